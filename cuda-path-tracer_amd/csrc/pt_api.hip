@@ -1,0 +1,641 @@
+/*
+ * pt_api.hip -- the C ABI of include/ptamd.h: scene construction / flattening / upload, the
+ * closest-hit and render entry points, device-memory helpers.  Host code only (kernels live in
+ * pt_kernels.hip and pt_post.hip).
+ */
+#include <cfloat>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "octree_build.h"
+#include "pt_internal.h"
+
+namespace ptamd {
+
+static thread_local std::string g_error;
+
+void set_error(const std::string &msg) { g_error = msg; }
+
+int hip_fail(hipError_t e, const char *what, const char *file, int line) {
+    char buf[512];
+    snprintf(buf, sizeof buf, "HIP error: %s (%s) at %s:%d", hipGetErrorString(e), what, file, line);
+    g_error = buf;
+    return 1;
+}
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t bytes = 0;
+};
+
+struct MaterialHost {
+    pt_material_desc d;
+    std::vector<uint8_t> maps[4];
+};
+
+struct EntityHost {
+    int shape = PT_SHAPE_MESH;
+    int material = 0;
+    int octree_depth = 0;
+    std::vector<float> positions, normals, uvs;
+    std::vector<int32_t> tri;
+    float aabb_min[3] = {0, 0, 0}, aabb_max[3] = {0, 0, 0};
+    float center[3] = {0, 0, 0};
+    float radius = 0;
+    FlatOctree tree;
+};
+
+} // namespace ptamd
+
+using namespace ptamd;
+
+struct pt_scene {
+    int device = 0;
+    int n_cu = 256;
+    std::vector<MaterialHost> materials;
+    std::vector<std::unique_ptr<EntityHost>> entities;
+    std::vector<float> hdri;
+    int hdri_w = 0, hdri_h = 0;
+    float hdri_exposure = 1.0f, hdri_contrast = 1.0f, hdri_rot = 0.0f;
+    bool has_hdri = false, hdri_smooth = false;
+
+    bool committed = false;
+    PtSceneDev dev{};
+    std::vector<void *> allocs;
+    uint64_t bytes_nodes = 0, bytes_tris = 0, bytes_shade = 0, bytes_tex = 0, bytes_hdri = 0;
+
+    DevBuf partials;                    /* render workspace, grown on demand */
+    uint32_t *d_counter = nullptr;
+    unsigned long long *d_stats = nullptr;
+
+    bool profiling = false;             /* bracket the render kernel with HIP events */
+    hipEvent_t ev_start = nullptr, ev_stop = nullptr;
+    bool ev_valid = false;
+};
+
+namespace {
+
+struct DeviceGuard {
+    int prev = -1;
+    bool ok = true;
+    explicit DeviceGuard(int dev) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != dev) ok = hipSetDevice(dev) == hipSuccess;
+    }
+    ~DeviceGuard() {
+        if (prev >= 0) (void)hipSetDevice(prev);
+    }
+};
+
+/* true when p can be dereferenced by a kernel on the current device */
+bool is_device_pointer(const void *p) {
+    hipPointerAttribute_t attr;
+    hipError_t e = hipPointerGetAttributes(&attr, p);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        return false;
+    }
+    return attr.type == hipMemoryTypeDevice || attr.type == hipMemoryTypeManaged;
+}
+
+template <typename T>
+int upload_vec(pt_scene *s, const std::vector<T> &v, const T **out, uint64_t *bytes_acc) {
+    *out = nullptr;
+    if (v.empty()) return 0;
+    void *d = nullptr;
+    PT_HIP(hipMalloc(&d, v.size() * sizeof(T)));
+    s->allocs.push_back(d);
+    PT_HIP(hipMemcpy(d, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+    if (bytes_acc) *bytes_acc += v.size() * sizeof(T);
+    *out = static_cast<const T *>(d);
+    return 0;
+}
+
+void free_device_side(pt_scene *s) {
+    for (void *p : s->allocs) (void)hipFree(p);
+    s->allocs.clear();
+    if (s->partials.p) (void)hipFree(s->partials.p);
+    s->partials = DevBuf();
+    if (s->d_counter) (void)hipFree(s->d_counter);
+    if (s->d_stats) (void)hipFree(s->d_stats);
+    s->d_counter = nullptr;
+    s->d_stats = nullptr;
+    if (s->ev_start) (void)hipEventDestroy(s->ev_start);
+    if (s->ev_stop) (void)hipEventDestroy(s->ev_stop);
+    s->ev_start = s->ev_stop = nullptr;
+    s->ev_valid = false;
+    s->committed = false;
+    s->bytes_nodes = s->bytes_tris = s->bytes_shade = s->bytes_tex = s->bytes_hdri = 0;
+}
+
+PtTriRec make_record(const float *pos, const int32_t *t, int32_t id) {
+    const float *v0 = pos + 3 * (size_t)t[0], *v1 = pos + 3 * (size_t)t[1], *v2 = pos + 3 * (size_t)t[2];
+    PtTriRec r;
+    r.v0x = v0[0]; r.v0y = v0[1]; r.v0z = v0[2];
+    /* e1 = v1 - v0, e2 = v2 - v0: the subtractions of src/device_geometry_functions.cuh:332-333 */
+    r.e1x = v1[0] - v0[0]; r.e1y = v1[1] - v0[1]; r.e1z = v1[2] - v0[2];
+    r.e2x = v2[0] - v0[0]; r.e2y = v2[1] - v0[1]; r.e2z = v2[2] - v0[2];
+    r.id = id; r.pad0 = 0; r.pad1 = 0;
+    return r;
+}
+
+void counters_from(const unsigned long long h[7], pt_counters *c) {
+    c->segments = h[0]; c->aabb_tests = h[1]; c->node_visits = h[2]; c->tri_tests = h[3];
+    c->env_lookups = h[4]; c->tex_fetches = h[5]; c->paths = h[6];
+}
+
+} // namespace
+
+extern "C" {
+
+const char *pt_last_error(void) { return g_error.c_str(); }
+
+int pt_device_count(int *count) {
+    if (!count) PT_FAIL("pt_device_count: null argument");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        n = 0;
+    }
+    *count = n;
+    return 0;
+}
+
+int pt_device_name(int device, char *buf, size_t cap) {
+    if (!buf || cap == 0) PT_FAIL("pt_device_name: null buffer");
+    hipDeviceProp_t prop;
+    PT_HIP(hipGetDeviceProperties(&prop, device));
+    snprintf(buf, cap, "%s", prop.name);
+    return 0;
+}
+
+int pt_scene_create(int device, pt_scene **out) {
+    if (!out) PT_FAIL("pt_scene_create: null argument");
+    /* device < 0: host-only scene (build and inspect octrees; cannot be committed) */
+    if (device >= 0) {
+        int n = 0;
+        PT_HIP(hipGetDeviceCount(&n));
+        if (device >= n) PT_FAIL("pt_scene_create: no such device");
+    }
+    pt_scene *s = new pt_scene();
+    s->device = device;
+    int cu = 0;
+    if (device >= 0 && hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cu > 0) s->n_cu = cu;
+    *out = s;
+    return 0;
+}
+
+int pt_scene_destroy(pt_scene *scene) {
+    if (!scene) return 0;
+    if (scene->device >= 0) {
+        DeviceGuard g(scene->device);
+        free_device_side(scene);
+    }
+    delete scene;
+    return 0;
+}
+
+int pt_scene_add_material(pt_scene *scene, const pt_material_desc *desc, int *material_out) {
+    if (!scene || !desc) PT_FAIL("pt_scene_add_material: null argument");
+    MaterialHost m;
+    m.d = *desc;
+    const uint8_t *src[4] = {desc->albedo_map, desc->specular_map, desc->normal_map, desc->smoothness_map};
+    const int w[4] = {desc->albedo_w, desc->specular_w, desc->normal_w, desc->smoothness_w};
+    const int h[4] = {desc->albedo_h, desc->specular_h, desc->normal_h, desc->smoothness_h};
+    for (int k = 0; k < 4; k++) {
+        if (!src[k]) continue;
+        if (w[k] <= 0 || h[k] <= 0) PT_FAIL("pt_scene_add_material: texture with non-positive size");
+        const size_t n = (size_t)w[k] * h[k] * (k == 3 ? 1 : 3);
+        m.maps[k].assign(src[k], src[k] + n);
+    }
+    scene->materials.push_back(std::move(m));
+    scene->committed = false;
+    if (material_out) *material_out = (int)scene->materials.size() - 1;
+    return 0;
+}
+
+int pt_scene_add_mesh(pt_scene *scene, const float *positions, const float *normals, int n_vertices, const int32_t *tri,
+                      int n_triangles, const float *uvs, int n_uvs, int material, int octree_depth, int *entity_out) {
+    if (!scene || !positions || !tri) PT_FAIL("pt_scene_add_mesh: null argument");
+    if (n_vertices <= 0 || n_triangles <= 0) PT_FAIL("pt_scene_add_mesh: empty mesh");
+    if (material < 0 || material >= (int)scene->materials.size()) PT_FAIL("pt_scene_add_mesh: unknown material");
+    if (octree_depth < 0 || octree_depth > PT_MAX_OCTREE_DEPTH) PT_FAIL("pt_scene_add_mesh: octree depth out of range");
+    for (int64_t i = 0; i < (int64_t)n_triangles; i++) {
+        for (int k = 0; k < 3; k++) {
+            const int32_t v = tri[6 * i + k];
+            if (v < 0 || v >= n_vertices) PT_FAIL("pt_scene_add_mesh: vertex index out of range");
+            if (n_uvs > 0) {
+                const int32_t t = tri[6 * i + 3 + k];
+                if (t < 0 || t >= n_uvs) PT_FAIL("pt_scene_add_mesh: uv index out of range");
+            }
+        }
+    }
+    std::unique_ptr<EntityHost> e(new EntityHost());
+    e->shape = PT_SHAPE_MESH;
+    e->material = material;
+    e->octree_depth = octree_depth;
+    e->positions.assign(positions, positions + 3 * (size_t)n_vertices);
+    e->tri.assign(tri, tri + 6 * (size_t)n_triangles);
+    if (uvs && n_uvs > 0) e->uvs.assign(uvs, uvs + 2 * (size_t)n_uvs);
+    e->normals.resize(3 * (size_t)n_vertices);
+    if (normals)
+        memcpy(e->normals.data(), normals, sizeof(float) * 3 * (size_t)n_vertices);
+    else
+        compute_vertex_normals(positions, n_vertices, tri, n_triangles, e->normals.data());
+    padded_aabb(positions, n_vertices, e->aabb_min, e->aabb_max);
+    if (octree_depth > 0) {
+        build_octree(e->positions.data(), e->tri.data(), n_triangles, e->aabb_min, e->aabb_max, octree_depth, e->tree);
+        if (e->tree.nodes.size() >= (1ull << 29)) PT_FAIL("pt_scene_add_mesh: octree too large (node index needs 29 bits)");
+    }
+    scene->entities.push_back(std::move(e));
+    scene->committed = false;
+    if (entity_out) *entity_out = (int)scene->entities.size() - 1;
+    return 0;
+}
+
+int pt_scene_add_sphere(pt_scene *scene, const float center[3], float radius, int material, int *entity_out) {
+    if (!scene || !center) PT_FAIL("pt_scene_add_sphere: null argument");
+    if (material < 0 || material >= (int)scene->materials.size()) PT_FAIL("pt_scene_add_sphere: unknown material");
+    std::unique_ptr<EntityHost> e(new EntityHost());
+    e->shape = PT_SHAPE_SPHERE;
+    e->material = material;
+    memcpy(e->center, center, sizeof(float) * 3);
+    e->radius = radius;
+    scene->entities.push_back(std::move(e));
+    scene->committed = false;
+    if (entity_out) *entity_out = (int)scene->entities.size() - 1;
+    return 0;
+}
+
+int pt_scene_set_hdri(pt_scene *scene, const float *rgb, int w, int h, float exposure, float contrast, float rot_offset, int smooth) {
+    if (!scene) PT_FAIL("pt_scene_set_hdri: null argument");
+    if (!rgb || w <= 0 || h <= 0) PT_FAIL("pt_scene_set_hdri: empty image");
+    if (!(rot_offset >= 0.0f)) PT_FAIL("pt_scene_set_hdri: rotation must be >= 0");   /* src/scene.cu:53 */
+    scene->hdri.assign(rgb, rgb + (size_t)w * h * 3);
+    scene->hdri_w = w; scene->hdri_h = h;
+    scene->hdri_exposure = exposure; scene->hdri_contrast = contrast;
+    scene->hdri_rot = fmodf(rot_offset, 1.0f);                                        /* src/scene.cu:54 */
+    scene->hdri_smooth = smooth != 0;
+    scene->has_hdri = true;
+    scene->committed = false;
+    return 0;
+}
+
+int pt_scene_commit(pt_scene *scene) {
+    if (!scene) PT_FAIL("pt_scene_commit: null argument");
+    if (scene->device < 0) PT_FAIL("pt_scene_commit: host-only scene (created with device < 0)");
+    DeviceGuard g(scene->device);
+    if (!g.ok) PT_FAIL("pt_scene_commit: cannot select device");
+    free_device_side(scene);
+
+    std::vector<PtEntity> ents(scene->entities.size());
+    std::vector<PtNode> nodes;
+    std::vector<PtTriRec> recs;
+    std::vector<PtShadeRec> shade;
+    int max_depth = 0;
+    for (size_t i = 0; i < scene->entities.size(); i++) {
+        const EntityHost &h = *scene->entities[i];
+        PtEntity e;
+        memset(&e, 0, sizeof e);
+        e.shape = h.shape;
+        e.material = h.material;
+        e.smooth_shading = scene->materials[h.material].d.smooth_shading ? 1 : 0;
+        memcpy(e.center, h.center, sizeof e.center);
+        e.radius = h.radius;
+        if (h.shape == PT_SHAPE_MESH) {
+            const int64_t nt = (int64_t)h.tri.size() / 6;
+            memcpy(e.aabb_min, h.aabb_min, sizeof e.aabb_min);
+            memcpy(e.aabb_max, h.aabb_max, sizeof e.aabb_max);
+            memcpy(e.region_min, h.aabb_min, sizeof e.region_min);
+            memcpy(e.region_max, h.aabb_max, sizeof e.region_max);
+            e.octree_depth = h.octree_depth;
+            e.has_uvs = h.uvs.empty() ? 0 : 1;
+            e.shade_base = (uint32_t)shade.size();
+            for (int64_t t = 0; t < nt; t++) {
+                const int32_t *tr = &h.tri[6 * t];
+                PtShadeRec sr;
+                memset(&sr, 0, sizeof sr);
+                memcpy(sr.n0, &h.normals[3 * (size_t)tr[0]], 12);
+                memcpy(sr.n1, &h.normals[3 * (size_t)tr[1]], 12);
+                memcpy(sr.n2, &h.normals[3 * (size_t)tr[2]], 12);
+                if (e.has_uvs) {
+                    memcpy(sr.uv0, &h.uvs[2 * (size_t)tr[3]], 8);
+                    memcpy(sr.uv1, &h.uvs[2 * (size_t)tr[4]], 8);
+                    memcpy(sr.uv2, &h.uvs[2 * (size_t)tr[5]], 8);
+                }
+                shade.push_back(sr);
+            }
+            if (h.octree_depth == 0) {
+                e.tri_first = (uint32_t)recs.size();
+                e.n_tris = (uint32_t)nt;
+                for (int64_t t = 0; t < nt; t++) recs.push_back(make_record(h.positions.data(), &h.tri[6 * t], (int32_t)t));
+            } else {
+                const uint32_t node_base = (uint32_t)nodes.size();
+                const uint32_t rec_base = (uint32_t)recs.size();
+                e.root_node = node_base;
+                const FlatOctree &T = h.tree;
+                const size_t n_inner = T.nodes.size() - (size_t)T.nodes_per_depth[T.max_depth];
+                for (size_t n = 0; n < T.nodes.size(); n++) {
+                    PtNode nd = T.nodes[n];
+                    nd.a += (n < n_inner) ? node_base : rec_base;
+                    nodes.push_back(nd);
+                }
+                for (int32_t t : T.leaf_tris) recs.push_back(make_record(h.positions.data(), &h.tri[6 * (size_t)t], t));
+                if (h.octree_depth > max_depth) max_depth = h.octree_depth;
+            }
+        }
+        ents[i] = e;
+    }
+    if (nodes.size() >= (1ull << 29) || recs.size() >= (1ull << 32)) PT_FAIL("pt_scene_commit: scene too large for 32-bit indices");
+
+    std::vector<PtMaterial> mats(scene->materials.size());
+    for (size_t i = 0; i < scene->materials.size(); i++) {
+        const MaterialHost &h = scene->materials[i];
+        PtMaterial m;
+        memset(&m, 0, sizeof m);
+        memcpy(m.albedo, h.d.albedo, 12);
+        memcpy(m.specular, h.d.specular, 12);
+        m.emission = h.d.emission;
+        m.smoothness = h.d.smoothness;
+        m.smooth_shading = h.d.smooth_shading ? 1 : 0;
+        const int w[4] = {h.d.albedo_w, h.d.specular_w, h.d.normal_w, h.d.smoothness_w};
+        const int hh[4] = {h.d.albedo_h, h.d.specular_h, h.d.normal_h, h.d.smoothness_h};
+        for (int k = 0; k < 4; k++) {
+            if (h.maps[k].empty()) continue;
+            const uint8_t *d = nullptr;
+            if (upload_vec(scene, h.maps[k], &d, &scene->bytes_tex)) return 1;
+            m.map[k] = d;
+            m.map_w[k] = w[k];
+            m.map_h[k] = hh[k];
+        }
+        mats[i] = m;
+    }
+
+    PtSceneDev d;
+    memset(&d, 0, sizeof d);
+    if (upload_vec(scene, ents, &d.entities, nullptr)) return 1;
+    if (upload_vec(scene, nodes, &d.nodes, &scene->bytes_nodes)) return 1;
+    if (upload_vec(scene, recs, &d.tris, &scene->bytes_tris)) return 1;
+    if (upload_vec(scene, shade, &d.shade, &scene->bytes_shade)) return 1;
+    if (upload_vec(scene, mats, &d.materials, nullptr)) return 1;
+    if (scene->has_hdri && upload_vec(scene, scene->hdri, &d.hdri, &scene->bytes_hdri)) return 1;
+    d.n_entities = (int32_t)ents.size();
+    d.hdri_w = scene->hdri_w; d.hdri_h = scene->hdri_h;
+    d.has_hdri = scene->has_hdri ? 1 : 0;
+    d.use_smooth_hdri = scene->hdri_smooth ? 1 : 0;
+    d.hdri_exposure = scene->hdri_exposure;
+    d.hdri_contrast = scene->hdri_contrast;
+    d.hdri_rot_offset = scene->hdri_rot;
+    d.max_depth = max_depth;
+    scene->dev = d;
+
+    PT_HIP(hipMalloc((void **)&scene->d_counter, sizeof(uint32_t)));
+    PT_HIP(hipMalloc((void **)&scene->d_stats, 7 * sizeof(unsigned long long)));
+    scene->committed = true;
+    return 0;
+}
+
+int pt_scene_octree_info(pt_scene *scene, int entity, pt_octree_info *info) {
+    if (!scene || !info) PT_FAIL("pt_scene_octree_info: null argument");
+    if (entity < 0 || entity >= (int)scene->entities.size()) PT_FAIL("pt_scene_octree_info: no such entity");
+    const EntityHost &h = *scene->entities[entity];
+    if (h.shape != PT_SHAPE_MESH || h.octree_depth == 0) PT_FAIL("pt_scene_octree_info: entity has no octree");
+    memset(info, 0, sizeof *info);
+    info->max_depth = h.tree.max_depth;
+    info->n_nodes = (int64_t)h.tree.nodes.size();
+    info->n_leaf_refs = (int64_t)h.tree.leaf_tris.size();
+    info->max_leaf = h.tree.max_leaf;
+    for (int i = 0; i <= h.tree.max_depth; i++) info->nodes_per_depth[i] = h.tree.nodes_per_depth[i];
+    return 0;
+}
+
+int pt_scene_octree_dump(pt_scene *scene, int entity, int32_t *out, int64_t cap, int64_t *n_words) {
+    if (!scene || !n_words) PT_FAIL("pt_scene_octree_dump: null argument");
+    if (entity < 0 || entity >= (int)scene->entities.size()) PT_FAIL("pt_scene_octree_dump: no such entity");
+    const EntityHost &h = *scene->entities[entity];
+    if (h.shape != PT_SHAPE_MESH || h.octree_depth == 0) PT_FAIL("pt_scene_octree_dump: entity has no octree");
+    std::vector<int32_t> d;
+    dump_octree(h.tree, d);
+    *n_words = (int64_t)d.size();
+    if (out) memcpy(out, d.data(), sizeof(int32_t) * (size_t)std::min<int64_t>(cap, (int64_t)d.size()));
+    return 0;
+}
+
+int pt_scene_device_bytes(pt_scene *scene, uint64_t *nodes, uint64_t *tri_records, uint64_t *shade_records,
+                          uint64_t *textures, uint64_t *hdri) {
+    if (!scene) PT_FAIL("pt_scene_device_bytes: null argument");
+    if (!scene->committed) PT_FAIL("pt_scene_device_bytes: scene not committed");
+    if (nodes) *nodes = scene->bytes_nodes;
+    if (tri_records) *tri_records = scene->bytes_tris;
+    if (shade_records) *shade_records = scene->bytes_shade;
+    if (textures) *textures = scene->bytes_tex;
+    if (hdri) *hdri = scene->bytes_hdri;
+    return 0;
+}
+
+int pt_trace_rays(pt_scene *scene, const float *rays, int64_t n, pt_hit *hits, int32_t *log, int log_stride,
+                  pt_counters *counters, void *stream_) {
+    if (!scene) PT_FAIL("pt_trace_rays: null scene");
+    if (!scene->committed) PT_FAIL("pt_trace_rays: scene not committed");
+    if (n < 0) PT_FAIL("pt_trace_rays: negative ray count");
+    if (n == 0) {
+        if (counters) memset(counters, 0, sizeof *counters);
+        return 0;
+    }
+    if (!rays || !hits) PT_FAIL("pt_trace_rays: null buffer");
+    if (log && log_stride < 1) PT_FAIL("pt_trace_rays: log_stride must be >= 1");
+    DeviceGuard g(scene->device);
+    hipStream_t stream = (hipStream_t)stream_;
+    const bool rays_dev = is_device_pointer(rays), hits_dev = is_device_pointer(hits);
+    const bool log_dev = log ? is_device_pointer(log) : true;
+    const float *d_rays = rays;
+    pt_hit *d_hits = hits;
+    int32_t *d_log = log;
+    void *tmp_rays = nullptr, *tmp_hits = nullptr, *tmp_log = nullptr;
+    int rc = 0;
+    do {
+        if (!rays_dev) {
+            if (hipMalloc(&tmp_rays, (size_t)n * 24) != hipSuccess) { rc = hip_fail(hipErrorOutOfMemory, "hipMalloc rays", __FILE__, __LINE__); break; }
+            if (hipMemcpyAsync(tmp_rays, rays, (size_t)n * 24, hipMemcpyHostToDevice, stream) != hipSuccess) { rc = 1; set_error("pt_trace_rays: ray upload failed"); break; }
+            d_rays = (const float *)tmp_rays;
+        }
+        if (!hits_dev) {
+            if (hipMalloc(&tmp_hits, (size_t)n * sizeof(pt_hit)) != hipSuccess) { rc = hip_fail(hipErrorOutOfMemory, "hipMalloc hits", __FILE__, __LINE__); break; }
+            d_hits = (pt_hit *)tmp_hits;
+        }
+        if (log && !log_dev) {
+            if (hipMalloc(&tmp_log, (size_t)n * log_stride * 4) != hipSuccess) { rc = hip_fail(hipErrorOutOfMemory, "hipMalloc log", __FILE__, __LINE__); break; }
+            d_log = (int32_t *)tmp_log;
+        }
+        if (counters && hipMemsetAsync(scene->d_stats, 0, 7 * sizeof(unsigned long long), stream) != hipSuccess) { rc = 1; set_error("pt_trace_rays: memset failed"); break; }
+        rc = launch_trace(scene->dev, d_rays, n, d_hits, d_log, log_stride, counters ? scene->d_stats : nullptr, stream);
+        if (rc) break;
+        if (!hits_dev && hipMemcpyAsync(hits, d_hits, (size_t)n * sizeof(pt_hit), hipMemcpyDeviceToHost, stream) != hipSuccess) { rc = 1; set_error("pt_trace_rays: hit download failed"); break; }
+        if (log && !log_dev && hipMemcpyAsync(log, d_log, (size_t)n * log_stride * 4, hipMemcpyDeviceToHost, stream) != hipSuccess) { rc = 1; set_error("pt_trace_rays: log download failed"); break; }
+        if (counters) {
+            unsigned long long h[7];
+            if (hipMemcpyAsync(h, scene->d_stats, sizeof h, hipMemcpyDeviceToHost, stream) != hipSuccess) { rc = 1; set_error("pt_trace_rays: counter download failed"); break; }
+            hipError_t e = hipStreamSynchronize(stream);
+            if (e != hipSuccess) { rc = hip_fail(e, "hipStreamSynchronize", __FILE__, __LINE__); break; }
+            counters_from(h, counters);
+        }
+        if (tmp_rays || tmp_hits || tmp_log) {
+            hipError_t e = hipStreamSynchronize(stream);
+            if (e != hipSuccess) { rc = hip_fail(e, "hipStreamSynchronize", __FILE__, __LINE__); break; }
+        }
+    } while (0);
+    if (tmp_rays) (void)hipFree(tmp_rays);
+    if (tmp_hits) (void)hipFree(tmp_hits);
+    if (tmp_log) (void)hipFree(tmp_log);
+    return rc;
+}
+
+int pt_camera_rays(int device, const pt_camera *camera, uint32_t seed, int sample, float *rays, void *stream_) {
+    if (!camera || !rays) PT_FAIL("pt_camera_rays: null argument");
+    if (camera->res_x <= 0 || camera->res_y <= 0) PT_FAIL("pt_camera_rays: empty image");
+    DeviceGuard g(device);
+    if (!g.ok) PT_FAIL("pt_camera_rays: cannot select device");
+    hipStream_t stream = (hipStream_t)stream_;
+    const size_t bytes = (size_t)camera->res_x * camera->res_y * 24;
+    if (is_device_pointer(rays)) return launch_camera_rays(*camera, seed, sample, rays, stream);
+    void *tmp = nullptr;
+    PT_HIP(hipMalloc(&tmp, bytes));
+    int rc = launch_camera_rays(*camera, seed, sample, (float *)tmp, stream);
+    if (!rc && hipMemcpyAsync(rays, tmp, bytes, hipMemcpyDeviceToHost, stream) != hipSuccess) { rc = 1; set_error("pt_camera_rays: download failed"); }
+    if (!rc && hipStreamSynchronize(stream) != hipSuccess) { rc = 1; set_error("pt_camera_rays: sync failed"); }
+    (void)hipFree(tmp);
+    return rc;
+}
+
+int pt_render_accumulate(pt_scene *scene, const pt_camera *camera, uint32_t seed, int sample_begin, int sample_end,
+                         int n_split, float *d_split, pt_counters *counters, void *stream_) {
+    if (!scene || !camera || !d_split) PT_FAIL("pt_render_accumulate: null argument");
+    if (!scene->committed) PT_FAIL("pt_render_accumulate: scene not committed");
+    if (camera->res_x <= 0 || camera->res_y <= 0) PT_FAIL("pt_render_accumulate: empty image");
+    if (sample_begin < 0 || sample_end < sample_begin) PT_FAIL("pt_render_accumulate: bad sample range");
+    if (n_split < 1 || n_split > 64) PT_FAIL("pt_render_accumulate: n_split must be in [1,64]");
+    if (!is_device_pointer(d_split)) PT_FAIL("pt_render_accumulate: d_split must be a device pointer");
+    if (sample_end == sample_begin) {
+        if (counters) memset(counters, 0, sizeof *counters);
+        return 0;
+    }
+    DeviceGuard g(scene->device);
+    hipStream_t stream = (hipStream_t)stream_;
+    RenderParams p;
+    memset(&p, 0, sizeof p);
+    p.sc = scene->dev;
+    p.cam = *camera;
+    p.seed = seed;
+    p.plan = make_slice_plan(sample_begin, sample_end, n_split);
+    p.tiles_x = (camera->res_x + 7) / 8;
+    p.tiles_y = (camera->res_y + 7) / 8;
+    const int n_slices = p.plan.n_split * p.plan.slices_per_split;
+    const uint64_t n_items = (uint64_t)p.tiles_x * p.tiles_y * n_slices;
+    if (n_items >= 0xFFFF0000ull) PT_FAIL("pt_render_accumulate: too many work items");
+    p.n_items = (uint32_t)n_items;
+    const int64_t n_pixels = (int64_t)camera->res_x * camera->res_y;
+    const size_t need = (size_t)n_slices * (size_t)n_pixels * 12;
+    if (scene->partials.bytes < need) {
+        /* the previous launch may still read the old workspace */
+        PT_HIP(hipStreamSynchronize(stream));
+        if (scene->partials.p) PT_HIP(hipFree(scene->partials.p));
+        scene->partials = DevBuf();
+        PT_HIP(hipMalloc(&scene->partials.p, need));
+        scene->partials.bytes = need;
+    }
+    p.partials = (float *)scene->partials.p;
+    p.counter = scene->d_counter;
+    p.stats = counters ? scene->d_stats : nullptr;
+    PT_HIP(hipMemsetAsync(scene->d_counter, 0, sizeof(uint32_t), stream));
+    if (counters) PT_HIP(hipMemsetAsync(scene->d_stats, 0, 7 * sizeof(unsigned long long), stream));
+    if (scene->profiling) {
+        if (!scene->ev_start) {
+            PT_HIP(hipEventCreate(&scene->ev_start));
+            PT_HIP(hipEventCreate(&scene->ev_stop));
+        }
+        PT_HIP(hipEventRecord(scene->ev_start, stream));
+    }
+    if (launch_render(p, scene->n_cu, stream)) return 1;
+    if (scene->profiling) {
+        PT_HIP(hipEventRecord(scene->ev_stop, stream));
+        scene->ev_valid = true;
+    }
+    if (launch_compound_partials(p.partials, d_split, n_pixels, p.plan, stream)) return 1;
+    if (counters) {
+        unsigned long long h[7];
+        PT_HIP(hipMemcpyAsync(h, scene->d_stats, sizeof h, hipMemcpyDeviceToHost, stream));
+        PT_HIP(hipStreamSynchronize(stream));
+        counters_from(h, counters);
+    }
+    return 0;
+}
+
+int pt_scene_set_profiling(pt_scene *scene, int enable) {
+    if (!scene) PT_FAIL("pt_scene_set_profiling: null argument");
+    scene->profiling = enable != 0;
+    scene->ev_valid = false;
+    return 0;
+}
+
+int pt_scene_last_render_kernel_ms(pt_scene *scene, float *ms) {
+    if (!scene || !ms) PT_FAIL("pt_scene_last_render_kernel_ms: null argument");
+    if (!scene->profiling || !scene->ev_valid) PT_FAIL("pt_scene_last_render_kernel_ms: no profiled render launch");
+    DeviceGuard g(scene->device);
+    PT_HIP(hipEventSynchronize(scene->ev_stop));
+    PT_HIP(hipEventElapsedTime(ms, scene->ev_start, scene->ev_stop));
+    return 0;
+}
+
+int pt_compound_buffers(int device, const float *d_split, float *d_out, int64_t n_pixels, int n_split, void *stream) {
+    if (!d_split || !d_out) PT_FAIL("pt_compound_buffers: null argument");
+    if (n_pixels < 0 || n_split < 1) PT_FAIL("pt_compound_buffers: bad size");
+    if (n_pixels == 0) return 0;
+    DeviceGuard g(device);
+    return launch_compound_split(d_split, d_out, n_pixels, n_split, (hipStream_t)stream);
+}
+
+int pt_malloc(int device, size_t bytes, void **d_ptr) {
+    if (!d_ptr) PT_FAIL("pt_malloc: null argument");
+    DeviceGuard g(device);
+    if (!g.ok) PT_FAIL("pt_malloc: cannot select device");
+    PT_HIP(hipMalloc(d_ptr, bytes ? bytes : 1));
+    return 0;
+}
+int pt_free(int device, void *d_ptr) {
+    if (!d_ptr) return 0;
+    DeviceGuard g(device);
+    PT_HIP(hipFree(d_ptr));
+    return 0;
+}
+int pt_memset(int device, void *d_ptr, int value, size_t bytes, void *stream) {
+    if (!d_ptr) PT_FAIL("pt_memset: null argument");
+    DeviceGuard g(device);
+    PT_HIP(hipMemsetAsync(d_ptr, value, bytes, (hipStream_t)stream));
+    return 0;
+}
+int pt_upload(int device, void *d_dst, const void *h_src, size_t bytes, void *stream) {
+    if (!d_dst || !h_src) PT_FAIL("pt_upload: null argument");
+    DeviceGuard g(device);
+    PT_HIP(hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, (hipStream_t)stream));
+    PT_HIP(hipStreamSynchronize((hipStream_t)stream));
+    return 0;
+}
+int pt_download(int device, void *h_dst, const void *d_src, size_t bytes, void *stream) {
+    if (!h_dst || !d_src) PT_FAIL("pt_download: null argument");
+    DeviceGuard g(device);
+    PT_HIP(hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, (hipStream_t)stream));
+    PT_HIP(hipStreamSynchronize((hipStream_t)stream));
+    return 0;
+}
+int pt_stream_synchronize(int device, void *stream) {
+    DeviceGuard g(device);
+    PT_HIP(hipStreamSynchronize((hipStream_t)stream));
+    return 0;
+}
+
+} // extern "C"

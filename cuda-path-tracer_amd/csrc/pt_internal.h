@@ -1,0 +1,61 @@
+/* pt_internal.h -- declarations shared between the translation units of libptamd.so */
+#ifndef PT_INTERNAL_H
+#define PT_INTERNAL_H
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+
+#include "../../include/ptamd.h"
+#include "pt_types.h"
+
+namespace ptamd {
+
+void set_error(const std::string &msg);
+int hip_fail(hipError_t e, const char *what, const char *file, int line);
+
+#define PT_HIP(call)                                                              \
+    do {                                                                          \
+        hipError_t e_ = (call);                                                   \
+        if (e_ != hipSuccess) return ::ptamd::hip_fail(e_, #call, __FILE__, __LINE__); \
+    } while (0)
+
+#define PT_FAIL(msg)                 \
+    do {                             \
+        ::ptamd::set_error(msg);     \
+        return 1;                    \
+    } while (0)
+
+/* how a sample range is cut into work items; a pure function of the range and n_split so that
+ * summation order never depends on launch geometry */
+struct SlicePlan {
+    int sample_begin;
+    int n_samples;
+    int n_split;
+    int slices_per_split;
+};
+SlicePlan make_slice_plan(int sample_begin, int sample_end, int n_split);
+
+struct RenderParams {
+    PtSceneDev sc;
+    pt_camera cam;
+    uint32_t seed;
+    SlicePlan plan;
+    int tiles_x, tiles_y;
+    uint32_t n_items;
+    uint32_t *counter;           /* work-item ticket, zeroed before the launch */
+    float *partials;             /* [n_split * slices_per_split][H*W][3] */
+    unsigned long long *stats;   /* 7 counters, or null */
+};
+
+/* kernel launchers (pt_kernels.hip); all asynchronous on `stream` */
+int launch_trace(const PtSceneDev &sc, const float *d_rays, int64_t n, pt_hit *d_hits, int32_t *d_log,
+                 int log_stride, unsigned long long *d_stats, hipStream_t stream);
+int launch_camera_rays(const pt_camera &cam, uint32_t seed, int sample, float *d_rays, hipStream_t stream);
+int launch_render(const RenderParams &p, int n_cu, hipStream_t stream);
+int launch_compound_partials(const float *d_partials, float *d_split, int64_t n_pixels, const SlicePlan &plan,
+                             hipStream_t stream);
+int launch_compound_split(const float *d_split, float *d_out, int64_t n_pixels, int n_split, hipStream_t stream);
+
+} // namespace ptamd
+#endif

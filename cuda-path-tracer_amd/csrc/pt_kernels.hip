@@ -1,0 +1,482 @@
+/*
+ * pt_kernels.hip -- closest-hit query kernel, primary-ray kernel, the persistent path-tracing
+ * kernel and the split-buffer compounding kernels (gfx950).
+ *
+ * Render kernel structure: a persistent grid (a few 256-thread workgroups per CU) whose waves pull
+ * work items {8x8-pixel tile, sample slice} from one global ticket.  A lane owns one pixel of an
+ * item and runs the slice's samples one after the other; every trip of the main loop advances each
+ * lane's path by ONE segment (closest hit + shading).  A lane whose path ended starts its next
+ * sample on the next trip, and a lane whose slice is finished immediately takes the next free
+ * pixel of the wave's current item (or of a freshly pulled one), so terminated paths never leave
+ * holes in the wave: the lanes stay compacted onto live rays until the ticket runs dry.  Each
+ * (pixel, slice) sum is written exactly once by its owner to a partial buffer and the partials are
+ * combined in fixed order afterwards -- no atomics on pixels, bit-reproducible images.
+ */
+#include "pt_device.h"
+#include "pt_internal.h"
+
+namespace ptamd {
+
+static constexpr int kBlock = 256;
+
+/* ------------------------------------------------------------------ shading (fast math allowed) */
+
+__device__ __forceinline__ float fast_rsq(float x) { return __builtin_amdgcn_rsqf(x); }
+__device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ V3 fast_normalized(V3 v) {
+    float r = fast_rsq(v.x * v.x + v.y * v.y + v.z * v.z);
+    return mk(v.x * r, v.y * r, v.z * r);
+}
+/* x^y for x in (0,1] (and 1000^y): v_log_f32 / v_exp_f32, like the reference's __powf */
+__device__ __forceinline__ float fast_pow(float x, float y) {
+    return __builtin_amdgcn_exp2f(y * __builtin_amdgcn_logf(x));
+}
+/* sin / cos of 2*pi*rev, rev in (0,1]: v_sin_f32 / v_cos_f32 take revolutions */
+__device__ __forceinline__ float sin_rev(float rev) { return __builtin_amdgcn_sinf(rev); }
+__device__ __forceinline__ float cos_rev(float rev) { return __builtin_amdgcn_cosf(rev); }
+
+__device__ __forceinline__ float luminosity(V3 c) { return c.x * 0.2126f + c.y * 0.7152f + c.z * 0.0722f; }  /* src/util.cuh:40 */
+
+__device__ __forceinline__ int to_index(float f, int n) {   /* C truncation, clamped into the image */
+    if (!(f >= 0.0f)) return 0;
+    if (f >= (float)n) return n - 1;
+    int i = (int)f;
+    return i > n - 1 ? n - 1 : i;
+}
+
+/* src/texture.cuh:22-43 (indices clamped into the texture) */
+__device__ __forceinline__ V3 tex_rgb(const uint8_t *data, int w, int h, float u, float v) {
+    const int x = to_index(u * (float)w, w);
+    const int y = to_index((1.0f - v) * (float)h, h);
+    const uint8_t *p = data + 3 * ((size_t)y * (size_t)w + (size_t)x);
+    return mk((float)p[0] / 255.0f, (float)p[1] / 255.0f, (float)p[2] / 255.0f);
+}
+__device__ __forceinline__ float tex_gray(const uint8_t *data, int w, int h, float u, float v) {
+    const int x = to_index(u * (float)w, w);
+    const int y = to_index((1.0f - v) * (float)h, h);
+    return (float)data[(size_t)y * (size_t)w + (size_t)x] / 255.0f;
+}
+
+/* src/scene.cuh:36-82 */
+__device__ __forceinline__ V3 sample_hdri(const PtSceneDev &sc, V3 v, Stats &st) {
+    if (!sc.has_hdri) return mk(0.f, 0.f, 0.f);
+    st.env_lookups++;
+    const int W = sc.hdri_w, H = sc.hdri_h;
+    const float rn = rsqrt_ieee(v.x * v.x + 0.0f + v.z * v.z);
+    const float vpx = v.x * rn, vpz = v.z * rn;
+    float x_c = ((acosf(vpz) * ((__float_as_uint(vpx) >> 31) ? -1.0f : 1.0f)) / (2.0f * 3.14159265f)) + 0.5f;
+    const float y_c = fminf(1.0f - ((v.y + 1.0f) / 2.0f), 0.99f);
+    x_c += sc.hdri_rot_offset;
+    x_c = fmodf(x_c, 1.0f);
+    const float *cols = sc.hdri;
+    V3 res;
+    if (!sc.use_smooth_hdri) {
+        const int x_i = to_index(x_c * (float)W, W), y_i = to_index(y_c * (float)H, H);
+        const float *p = cols + 3 * ((size_t)y_i * W + x_i);
+        res = mk(p[0], p[1], p[2]);
+    } else {
+        const int x_l = to_index(x_c * (float)W, W), y_l = to_index(y_c * (float)H, H);
+        const int x_r = (x_l + 1) % W, y_r = (y_l + 1) % H;
+        const float xw = fminf(fmaxf(x_c * (float)W - (float)x_l, 0.0f), 1.0f);
+        const float yw = fminf(fmaxf(y_c * (float)H - (float)y_l, 0.0f), 1.0f);
+        const float *ul = cols + 3 * ((size_t)y_l * W + x_l), *ur = cols + 3 * ((size_t)y_l * W + x_r);
+        const float *ll = cols + 3 * ((size_t)y_r * W + x_l), *lr = cols + 3 * ((size_t)y_r * W + x_r);
+        /* bilerp of src/math_util.cuh:20-24: lerp(lerp(ul,ll,v), lerp(ur,lr,v), u) */
+        float o[3];
+        for (int k = 0; k < 3; k++) {
+            const float left = (1.0f - yw) * ul[k] + yw * ll[k];
+            const float right = (1.0f - yw) * ur[k] + yw * lr[k];
+            o[k] = (1.0f - xw) * left + xw * right;
+        }
+        res = mk(o[0], o[1], o[2]);
+    }
+    if (sc.hdri_contrast != 1.0f) {
+        res.x = powf(res.x, sc.hdri_contrast);
+        res.y = powf(res.y, sc.hdri_contrast);
+        res.z = powf(res.z, sc.hdri_contrast);
+    }
+    return sc.hdri_exposure * res;
+}
+
+struct Basis { V3 t, b, n; };
+/* src/renderer.cu:168-175 */
+__device__ __forceinline__ Basis tangent_space(V3 n) {
+    V3 helper = mk(1.f, 0.f, 0.f);
+    if (fabsf(n.x) > 0.99f) helper = mk(0.f, 0.f, 1.f);
+    Basis B;
+    B.t = fast_normalized(cross3(n, helper));
+    B.b = fast_normalized(cross3(n, B.t));
+    B.n = n;
+    return B;
+}
+/* vec3 * mat3(t,b,n) of src/vector.cuh:186-192 */
+__device__ __forceinline__ V3 to_world(V3 v, const Basis &B) {
+    return mk(v.x * B.t.x + v.y * B.b.x + v.z * B.n.x, v.x * B.t.y + v.y * B.b.y + v.z * B.n.y,
+              v.x * B.t.z + v.y * B.b.z + v.z * B.n.z);
+}
+/* src/renderer.cu:157-163 */
+__device__ __forceinline__ V3 sample_hemisphere(V3 dir, float alpha, float xi_c, float xi_p) {
+    const float cos_theta = fast_pow(xi_c, fast_rcp(alpha + 1.0f));
+    const float sin_theta = __builtin_sqrtf(fmaxf(1.0f - cos_theta * cos_theta, 0.0f));
+    const V3 ts = mk(cos_rev(xi_p) * sin_theta, sin_rev(xi_p) * sin_theta, cos_theta);
+    return to_world(ts, tangent_space(dir));
+}
+
+/* src/renderer.cu:60-87; xi = Philox block 0 of (pixel, sample) */
+__device__ __forceinline__ void camera_ray(const pt_camera &cam, int u, int v, const float xi[4], V3 &ro, V3 &rd) {
+    const V3 pos = mk(cam.position[0], cam.position[1], cam.position[2]);
+    const V3 dir = mk(cam.direction[0], cam.direction[1], cam.direction[2]);
+    const V3 up = mk(cam.up[0], cam.up[1], cam.up[2]);
+    const float n_u = (((float)u + xi[0]) / (float)cam.res_x) - 0.5f;
+    const float n_v = (((float)v + xi[1]) / (float)cam.res_y) - 0.5f;
+    const float aspect = (float)cam.res_x / (float)cam.res_y;
+    const V3 c = cross3(dir, up);
+    const V3 right = mk(-c.x, -c.y, -c.z);
+    const V3 point = (((aspect * (n_u * right)) - (n_v * up)) + pos) + (cam.focal_length * dir);
+    V3 ray_dir = normalized(point - pos);
+    V3 ray_orig = pos;
+    if (cam.aperture > 0.01f) {
+        const float r = __builtin_sqrtf(xi[2]) * (cam.aperture / 2);
+        const float dx = cos_rev(xi[3]) * r, dy = sin_rev(xi[3]) * r;
+        const V3 off = (dx * right) - (dy * up);
+        const V3 focal_point = ray_orig + (cam.focus_distance * (1.0f / dot3(dir, ray_dir))) * ray_dir;
+        ray_orig = ray_orig + off;
+        ray_dir = normalized(focal_point - ray_orig);
+    }
+    ro = ray_orig; rd = ray_dir;
+}
+
+/* One bounce of color() (src/renderer.cu:106-138) after a hit: samples the material, plays the
+ * specular/diffuse roulette and replaces the ray.  xi = Philox block 1+bounce. */
+__device__ __forceinline__ void shade_hit(const PtSceneDev &sc, const Best &best, const Surface &sf, const float xi[4],
+                                          V3 &o, V3 &d, V3 &atten, V3 &result, Stats &st) {
+    const PtMaterial &m = sc.materials[sc.entities[best.entity].material];
+    V3 ts_normal = mk(0.f, 0.f, 1.f);
+    if (m.map[2]) {
+        st.tex_fetches++;
+        const V3 c = tex_rgb(m.map[2], m.map_w[2], m.map_h[2], sf.u, sf.v);
+        ts_normal = fast_normalized(mk(2.0f * c.x - 1.0f, 2.0f * c.y - 1.0f, 2.0f * c.z - 1.0f));
+    }
+    V3 albedo = mk(m.albedo[0], m.albedo[1], m.albedo[2]);
+    if (m.map[0]) { st.tex_fetches++; albedo = tex_rgb(m.map[0], m.map_w[0], m.map_h[0], sf.u, sf.v); }
+    float smoothness = m.smoothness;
+    if (m.map[3]) { st.tex_fetches++; smoothness = tex_gray(m.map[3], m.map_w[3], m.map_h[3], sf.u, sf.v); }
+    V3 specular = mk(m.specular[0], m.specular[1], m.specular[2]);
+    if (m.map[1]) { st.tex_fetches++; specular = tex_rgb(m.map[1], m.map_w[1], m.map_h[1], sf.u, sf.v); }
+    const float emission = m.emission;
+    const V3 normal = to_world(ts_normal, tangent_space(sf.normal));
+
+    albedo = mk(fminf(1.0f - specular.x, albedo.x), fminf(1.0f - specular.y, albedo.y), fminf(1.0f - specular.z, albedo.z));
+    float spec_chance = luminosity(specular);
+    float diff_chance = luminosity(albedo);
+    const float sum = spec_chance + diff_chance;
+    spec_chance /= sum;
+    diff_chance /= sum;
+    const float roulette = xi[0];
+    o = sf.position + 0.001f * normal;
+    if (roulette < spec_chance) {
+        const float alpha = __builtin_amdgcn_exp2f(smoothness * smoothness * 9.965784284662087f);   /* 1000^(s^2) */
+        const float dn = dot3(d, normal);
+        const V3 refl = d - (2.0f * dn) * normal;                                                   /* renderer.cu:147-149 */
+        d = sample_hemisphere(refl, alpha, xi[1], xi[2]);
+        const float f = (alpha + 2.0f) / (alpha + 1.0f);
+        const float k = (1.0f / spec_chance) * f * dot3(normal, d);
+        atten = mk(atten.x * specular.x * k, atten.y * specular.y * k, atten.z * specular.z * k);
+    } else {
+        result = result + emission * (albedo * atten);
+        d = sample_hemisphere(normal, 1.0f, xi[1], xi[2]);
+        const float k = 1.0f / diff_chance;
+        atten = mk(atten.x * albedo.x * k, atten.y * albedo.y * k, atten.z * albedo.z * k);
+    }
+}
+
+/* counters: reduce over the wave, one atomic per wave and counter */
+__device__ __forceinline__ void flush_stat(unsigned long long *dst, uint32_t v) {
+    unsigned long long x = v;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off);
+    if ((threadIdx.x & 63) == 0) atomicAdd(dst, x);
+}
+
+/* ------------------------------------------------------------------ closest-hit query kernel */
+template <bool LOG>
+__global__ void __launch_bounds__(kBlock) trace_kernel(PtSceneDev sc, const float *__restrict__ rays, int64_t n,
+                                                       pt_hit *__restrict__ hits, int32_t *__restrict__ log, int log_stride,
+                                                       unsigned long long *__restrict__ stats) {
+    extern __shared__ float4 lds_stack[];
+    float4 *stack = lds_stack + threadIdx.x;
+    Stats st;
+    stats_zero(st);
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
+        const V3 o = mk(rays[6 * i], rays[6 * i + 1], rays[6 * i + 2]);
+        const V3 d = mk(rays[6 * i + 3], rays[6 * i + 4], rays[6 * i + 5]);
+        TriLog lg;
+        lg.p = LOG ? log + i * log_stride : nullptr;
+        lg.cap = log_stride;
+        if (LOG) lg.p[0] = 0;
+        Best best;
+        const bool h = closest_hit<LOG>(sc, o, d, best, st, lg, stack, kBlock);
+        pt_hit out;
+        out.entity = -1; out.triangle = -1; out.t = best.t;
+        out.bu = out.bv = out.u = out.v = 0.f;
+        out.position[0] = out.position[1] = out.position[2] = 0.f;
+        out.normal[0] = out.normal[1] = out.normal[2] = 0.f;
+        if (h) {
+            Surface sf;
+            finish_hit(sc, o, d, best, sf);
+            out.entity = best.entity; out.triangle = best.tri;
+            out.bu = best.bu; out.bv = best.bv; out.u = sf.u; out.v = sf.v;
+            out.position[0] = sf.position.x; out.position[1] = sf.position.y; out.position[2] = sf.position.z;
+            out.normal[0] = sf.normal.x; out.normal[1] = sf.normal.y; out.normal[2] = sf.normal.z;
+        }
+        hits[i] = out;
+    }
+    if (stats) {
+        flush_stat(&stats[0], st.segments);
+        flush_stat(&stats[1], st.aabb_tests);
+        flush_stat(&stats[2], st.node_visits);
+        flush_stat(&stats[3], st.tri_tests);
+    }
+}
+
+__global__ void __launch_bounds__(kBlock) camera_rays_kernel(pt_camera cam, uint32_t seed, int sample, float *__restrict__ rays) {
+    const int n = cam.res_x * cam.res_y;
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    float xi[4];
+    rng_block((uint32_t)i, (uint32_t)sample, 0u, seed, xi);
+    V3 o, d;
+    camera_ray(cam, i % cam.res_x, i / cam.res_x, xi, o, d);
+    float *r = rays + 6 * (size_t)i;
+    r[0] = o.x; r[1] = o.y; r[2] = o.z; r[3] = d.x; r[4] = d.y; r[5] = d.z;
+}
+
+/* ------------------------------------------------------------------ persistent render kernel */
+__device__ __forceinline__ void slice_range(const SlicePlan &pl, int slice, int &s0, int &s1) {
+    const int z = slice / pl.slices_per_split, j = slice - z * pl.slices_per_split;
+    const long long N = pl.n_samples;
+    const int zb = pl.sample_begin + (int)((N * z) / pl.n_split);
+    const int ze = pl.sample_begin + (int)((N * (z + 1)) / pl.n_split);
+    const long long M = ze - zb;
+    s0 = zb + (int)((M * j) / pl.slices_per_split);
+    s1 = zb + (int)((M * (j + 1)) / pl.slices_per_split);
+}
+
+__global__ void __launch_bounds__(kBlock) render_kernel(RenderParams P) {
+    extern __shared__ float4 lds_stack[];
+    float4 *stack = lds_stack + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int W = P.cam.res_x, H = P.cam.res_y;
+    const int n_slices = P.plan.n_split * P.plan.slices_per_split;
+    const size_t n_pixels = (size_t)W * (size_t)H;
+
+    /* wave-uniform pool: the item this wave is handing out pixels of */
+    uint32_t pool_item = 0;
+    int pool_next = 64;
+    bool exhausted = false;
+
+    /* lane state */
+    int pixel = -1, px = 0, py = 0, slice = 0, s_cur = 0, s_end = 0;
+    bool done = false, path_active = false;
+    V3 accum = mk(0.f, 0.f, 0.f), result = mk(0.f, 0.f, 0.f), atten = mk(1.f, 1.f, 1.f);
+    V3 o = mk(0.f, 0.f, 0.f), d = mk(0.f, 0.f, 1.f);
+    int bounce = 0;
+    Stats st;
+    stats_zero(st);
+    TriLog lg;
+    lg.p = nullptr; lg.cap = 0;
+
+    for (;;) {
+        if (!path_active && pixel >= 0 && s_cur >= s_end) {
+            float *out = P.partials + 3 * ((size_t)slice * n_pixels + (size_t)pixel);
+            out[0] = accum.x; out[1] = accum.y; out[2] = accum.z;
+            pixel = -1;
+        }
+        const bool wants = !path_active && !done && pixel < 0;
+        const unsigned long long need = __ballot(wants);
+        if (need != 0ull) {
+            const int n_need = __popcll(need);
+            const int rank = __popcll(need & ((1ull << lane) - 1ull));
+            int assigned = 0;
+            bool got = false;
+            uint32_t my_item = 0;
+            int my_slot = 0;
+            while (assigned < n_need) {
+                if (pool_next >= 64) {
+                    if (exhausted) break;
+                    uint32_t id = 0;
+                    if (lane == 0) id = atomicAdd(P.counter, 1u);
+                    id = (uint32_t)__builtin_amdgcn_readfirstlane((int)id);
+                    if (id >= P.n_items) { exhausted = true; break; }
+                    pool_item = id;
+                    pool_next = 0;
+                }
+                const int k = min(n_need - assigned, 64 - pool_next);
+                if (wants && rank >= assigned && rank < assigned + k) {
+                    got = true;
+                    my_item = pool_item;
+                    my_slot = pool_next + (rank - assigned);
+                }
+                pool_next += k;
+                assigned += k;
+            }
+            if (wants) {
+                if (!got) {
+                    done = true;
+                } else {
+                    const uint32_t tile = my_item / (uint32_t)n_slices;
+                    slice = (int)(my_item - tile * (uint32_t)n_slices);
+                    const int tx = (int)(tile % (uint32_t)P.tiles_x), ty = (int)(tile / (uint32_t)P.tiles_x);
+                    px = tx * 8 + (my_slot & 7);
+                    py = ty * 8 + (my_slot >> 3);
+                    if (px < W && py < H) {
+                        pixel = py * W + px;
+                        slice_range(P.plan, slice, s_cur, s_end);
+                        accum = mk(0.f, 0.f, 0.f);
+                    }
+                }
+            }
+        }
+        if (!path_active && pixel >= 0 && s_cur < s_end) {
+            float xi[4];
+            rng_block((uint32_t)pixel, (uint32_t)s_cur, 0u, P.seed, xi);
+            camera_ray(P.cam, px, py, xi, o, d);
+            atten = mk(1.f, 1.f, 1.f);
+            result = mk(0.f, 0.f, 0.f);
+            bounce = 0;
+            path_active = true;
+            st.paths++;
+        }
+        if (__ballot(path_active) == 0ull) {
+            if (__ballot(!done) == 0ull) break;
+            continue;
+        }
+        if (path_active) {
+            Best best;
+            const bool h = closest_hit<false>(P.sc, o, d, best, st, lg, stack, kBlock);
+            bool ended;
+            if (!h) {
+                const V3 env = sample_hdri(P.sc, d, st);
+                result = result + atten * env;
+                ended = true;
+            } else {
+                Surface sf;
+                finish_hit(P.sc, o, d, best, sf);
+                float xi[4];
+                rng_block((uint32_t)pixel, (uint32_t)s_cur, 1u + (uint32_t)bounce, P.seed, xi);
+                shade_hit(P.sc, best, sf, xi, o, d, atten, result, st);
+                bounce++;
+                ended = bounce >= 6;   /* src/renderer.cu:99 */
+            }
+            if (ended) {
+                accum = accum + result;
+                s_cur++;
+                path_active = false;
+            }
+        }
+    }
+    if (P.stats) {
+        flush_stat(&P.stats[0], st.segments);
+        flush_stat(&P.stats[1], st.aabb_tests);
+        flush_stat(&P.stats[2], st.node_visits);
+        flush_stat(&P.stats[3], st.tri_tests);
+        flush_stat(&P.stats[4], st.env_lookups);
+        flush_stat(&P.stats[5], st.tex_fetches);
+        flush_stat(&P.stats[6], st.paths);
+    }
+}
+
+/* split[z][p] += sum_j partial[z * slices_per_split + j][p], j ascending */
+__global__ void __launch_bounds__(kBlock) compound_partials_kernel(const float *__restrict__ partials, float *__restrict__ split,
+                                                                   int64_t n_floats, int n_split, int slices_per_split) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n_floats) return;
+    for (int z = 0; z < n_split; z++) {
+        float s = 0.0f;
+        for (int j = 0; j < slices_per_split; j++) s = s + partials[(int64_t)(z * slices_per_split + j) * n_floats + i];
+        split[(int64_t)z * n_floats + i] = split[(int64_t)z * n_floats + i] + s;
+    }
+}
+
+/* compound_buffers (src/post_processing.cu:243-256) */
+__global__ void __launch_bounds__(kBlock) compound_split_kernel(const float *__restrict__ split, float *__restrict__ out,
+                                                                int64_t n_floats, int n_split) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n_floats) return;
+    float s = 0.0f;
+    for (int z = 0; z < n_split; z++) s = s + split[(int64_t)z * n_floats + i];
+    out[i] = s;
+}
+
+/* ------------------------------------------------------------------ launchers */
+SlicePlan make_slice_plan(int sample_begin, int sample_end, int n_split) {
+    SlicePlan p;
+    p.sample_begin = sample_begin;
+    p.n_samples = sample_end - sample_begin;
+    p.n_split = n_split;
+    const int per_split = (p.n_samples + n_split - 1) / n_split;
+    /* slices of about 32 samples, at most 32 slices per split buffer */
+    int s = (per_split + 31) / 32;
+    if (s > 32) s = 32;
+    if (s < 1) s = 1;
+    p.slices_per_split = s;
+    return p;
+}
+
+static size_t stack_bytes(int max_depth) { return (size_t)(max_depth > 0 ? max_depth : 1) * kBlock * sizeof(float4); }
+
+int launch_trace(const PtSceneDev &sc, const float *d_rays, int64_t n, pt_hit *d_hits, int32_t *d_log, int log_stride,
+                 unsigned long long *d_stats, hipStream_t stream) {
+    if (n <= 0) return 0;
+    int64_t blocks = (n + kBlock - 1) / kBlock;
+    if (blocks > 256 * 8) blocks = 256 * 8;
+    const size_t lds = stack_bytes(sc.max_depth);
+    if (d_log)
+        hipLaunchKernelGGL(trace_kernel<true>, dim3((unsigned)blocks), dim3(kBlock), lds, stream, sc, d_rays, n, d_hits, d_log, log_stride, d_stats);
+    else
+        hipLaunchKernelGGL(trace_kernel<false>, dim3((unsigned)blocks), dim3(kBlock), lds, stream, sc, d_rays, n, d_hits, d_log, log_stride, d_stats);
+    PT_HIP(hipGetLastError());
+    return 0;
+}
+
+int launch_camera_rays(const pt_camera &cam, uint32_t seed, int sample, float *d_rays, hipStream_t stream) {
+    const int n = cam.res_x * cam.res_y;
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(camera_rays_kernel, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, cam, seed, sample, d_rays);
+    PT_HIP(hipGetLastError());
+    return 0;
+}
+
+int launch_render(const RenderParams &p, int n_cu, hipStream_t stream) {
+    const size_t lds = stack_bytes(p.sc.max_depth);
+    /* persistent grid: as many workgroups as stay resident (registers allow 4 waves per SIMD =
+     * 4 workgroups of 256 threads per CU; LDS allows 160 KiB / lds) */
+    int per_cu = 4;
+    const int by_lds = (int)((160 * 1024) / (lds ? lds : 1));
+    if (by_lds < per_cu) per_cu = by_lds > 0 ? by_lds : 1;
+    int64_t blocks = (int64_t)n_cu * per_cu;
+    const int64_t max_useful = ((int64_t)p.n_items * 64 + kBlock - 1) / kBlock;
+    if (blocks > max_useful) blocks = max_useful;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(render_kernel, dim3((unsigned)blocks), dim3(kBlock), lds, stream, p);
+    PT_HIP(hipGetLastError());
+    return 0;
+}
+
+int launch_compound_partials(const float *d_partials, float *d_split, int64_t n_pixels, const SlicePlan &plan, hipStream_t stream) {
+    const int64_t n_floats = n_pixels * 3;
+    hipLaunchKernelGGL(compound_partials_kernel, dim3((unsigned)((n_floats + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream,
+                       d_partials, d_split, n_floats, plan.n_split, plan.slices_per_split);
+    PT_HIP(hipGetLastError());
+    return 0;
+}
+
+int launch_compound_split(const float *d_split, float *d_out, int64_t n_pixels, int n_split, hipStream_t stream) {
+    const int64_t n_floats = n_pixels * 3;
+    hipLaunchKernelGGL(compound_split_kernel, dim3((unsigned)((n_floats + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream, d_split,
+                       d_out, n_floats, n_split);
+    PT_HIP(hipGetLastError());
+    return 0;
+}
+
+} // namespace ptamd

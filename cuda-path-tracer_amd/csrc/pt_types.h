@@ -1,0 +1,87 @@
+/*
+ * pt_types.h -- device-visible data layout shared by the host scene builder and the HIP kernels.
+ *
+ * Layout in HBM (everything is a flat array; entities index into them by base offsets):
+ *   nodes[]   8 B per octree node, breadth-first per entity, the (up to 8) children of a node
+ *             stored contiguously in slot order.  inner: {first child index, child mask};
+ *             leaf (depth == entity's octree depth): {first triangle record, record count}.
+ *   tris[]    48 B pre-gathered triangle records {v0, e1 = v1-v0, e2 = v2-v0, id}; one run per
+ *             leaf (a triangle is repeated in every leaf it overlaps, ascending id inside a leaf),
+ *             or one run in index order for a mesh without octree.  Three 16-byte loads per test
+ *             instead of the reference's index -> Triangle -> 3 x Vertex pointer chase
+ *             (src/device_geometry_functions.cuh:148-154).
+ *   shade[]   64 B per unique triangle {3 vertex normals, 3 uvs}: read once per accepted hit.
+ */
+#ifndef PT_TYPES_H
+#define PT_TYPES_H
+
+#include <stdint.h>
+
+#define PT_SHAPE_SPHERE 0
+#define PT_SHAPE_MESH 1
+
+struct PtNode {
+    uint32_t a;   /* inner: index of first child;   leaf: index of first triangle record */
+    uint32_t b;   /* inner: 8-bit child mask;       leaf: number of records */
+};
+
+struct alignas(16) PtTriRec {
+    float v0x, v0y, v0z, e1x;
+    float e1y, e1z, e2x, e2y;
+    float e2z;
+    int32_t id;        /* triangle index inside its entity */
+    int32_t pad0, pad1;
+};
+
+struct alignas(16) PtShadeRec {
+    float n0[3], n1[3], n2[3];
+    float uv0[2], uv1[2], uv2[2];
+    float pad;
+};
+
+struct alignas(16) PtEntity {
+    int32_t  shape;
+    int32_t  material;
+    int32_t  octree_depth;     /* 0 = brute force */
+    uint32_t root_node;        /* index into nodes[] */
+    float    aabb_min[3];
+    uint32_t tri_first;        /* brute force: first record */
+    float    aabb_max[3];
+    uint32_t n_tris;           /* brute force: number of records */
+    float    region_min[3];    /* octree root region (the entity AABB when the octree was built) */
+    uint32_t shade_base;
+    float    region_max[3];
+    int32_t  has_uvs;
+    float    center[3];
+    float    radius;
+    int32_t  smooth_shading;
+    int32_t  pad[3];
+};
+
+struct PtMaterial {
+    float albedo[3];
+    float emission;
+    float specular[3];
+    float smoothness;
+    int32_t smooth_shading;
+    int32_t pad;
+    const uint8_t *map[4];     /* albedo, specular, normal (RGB8), smoothness (G8); null = unset */
+    int32_t map_w[4];
+    int32_t map_h[4];
+};
+
+struct PtSceneDev {
+    const PtEntity   *entities;
+    const PtNode     *nodes;
+    const PtTriRec   *tris;
+    const PtShadeRec *shade;
+    const PtMaterial *materials;
+    const float      *hdri;    /* h x w x 3 */
+    int32_t n_entities;
+    int32_t hdri_w, hdri_h;
+    int32_t has_hdri, use_smooth_hdri;
+    float   hdri_exposure, hdri_contrast, hdri_rot_offset;
+    int32_t max_depth;         /* deepest octree in the scene: sizes the per-lane stack */
+};
+
+#endif

@@ -121,11 +121,12 @@ def tri6(faces, vt=None):
 # ----------------------------------------------------------------------------- procedural assets
 def _hash01(ix, iy, seed):
     """Deterministic integer-lattice hash -> [0,1) (uint32 arithmetic, platform independent)."""
-    h = (ix.astype(np.uint32) * np.uint32(374761393) + iy.astype(np.uint32) * np.uint32(668265263)
-         + np.uint32(seed) * np.uint32(2246822519))
-    h = (h ^ (h >> np.uint32(13))) * np.uint32(1274126177)
-    h = h ^ (h >> np.uint32(16))
-    return (h >> np.uint32(8)).astype(np.float64) / float(1 << 24)
+    m = np.uint64(0xFFFFFFFF)
+    h = (ix.astype(np.uint64) * np.uint64(374761393) + iy.astype(np.uint64) * np.uint64(668265263)
+         + np.uint64((int(seed) * 2246822519) & 0xFFFFFFFF)) & m
+    h = ((h ^ (h >> np.uint64(13))) * np.uint64(1274126177)) & m
+    h = h ^ (h >> np.uint64(16))
+    return (h >> np.uint64(8)).astype(np.float64) / float(1 << 24)
 
 
 def value_noise(u, v, freq, seed, periodic_u=True):
@@ -228,42 +229,72 @@ def grid_terrain(n, size, amp, seed):
     return pos, faces, uv
 
 
+def _upsample(a, factor):
+    """Bilinear upsampling of a 2-D (or HxWxC) array by an integer factor (periodic borders)."""
+    if factor == 1:
+        return a
+    h, w = a.shape[0], a.shape[1]
+    ys = (np.arange(h * factor) + 0.5) / factor - 0.5
+    xs = (np.arange(w * factor) + 0.5) / factor - 0.5
+    y0 = np.floor(ys).astype(np.int64)
+    x0 = np.floor(xs).astype(np.int64)
+    fy = (ys - y0).astype(np.float32)
+    fx = (xs - x0).astype(np.float32)
+    y0m, y1m = y0 % h, (y0 + 1) % h
+    x0m, x1m = x0 % w, (x0 + 1) % w
+    a = a.astype(np.float32)
+    shape_y = (-1, 1) + (1,) * (a.ndim - 2)
+    rows = a[y0m] * (1 - fy).reshape(shape_y) + a[y1m] * fy.reshape(shape_y)
+    shape_x = (1, -1) + (1,) * (a.ndim - 2)
+    return rows[:, x0m] * (1 - fx).reshape(shape_x) + rows[:, x1m] * fx.reshape(shape_x)
+
+
 def procedural_textures(res, seed=3):
     """Albedo / normal (RGB8) and gloss (G8) maps standing in for the reference's missing
-    examples/hcandersen/textures/{diff,normal,gloss}.jpg."""
-    s = (np.arange(res) + 0.5) / res
+    examples/hcandersen/textures/{diff,normal,gloss}.jpg.  The noise is evaluated on a grid of at
+    most 512^2 and upsampled, so building 4096^2 maps takes seconds."""
+    base = min(res, 512)
+    factor = max(1, res // base)
+    res = base * factor
+    s = (np.arange(base) + 0.5) / base
     U, Vv = np.meshgrid(s, s, indexing="xy")
     n1 = fbm(U, Vv, 5, seed, base=8)
     n2 = fbm(U, Vv, 4, seed + 101, base=16)
+    hgt = fbm(U, Vv, 6, seed + 202, base=8)
+    n1, n2, hgt = _upsample(n1, factor), _upsample(n2, factor), _upsample(hgt, factor)
     albedo = np.stack([0.55 + 0.35 * n1, 0.45 + 0.35 * n2, 0.35 + 0.3 * n1 * n2], axis=-1)
     albedo = np.clip(albedo * 255.0, 0, 255).astype(np.uint8)
-    hgt = fbm(U, Vv, 6, seed + 202, base=8)
-    dx = np.roll(hgt, -1, axis=1) - np.roll(hgt, 1, axis=1)
-    dy = np.roll(hgt, -1, axis=0) - np.roll(hgt, 1, axis=0)
-    nrm = np.stack([-dx * res * 0.02, -dy * res * 0.02, np.ones_like(dx)], axis=-1)
+    dx = np.roll(hgt, -factor, axis=1) - np.roll(hgt, factor, axis=1)
+    dy = np.roll(hgt, -factor, axis=0) - np.roll(hgt, factor, axis=0)
+    nrm = np.stack([-dx * base * 0.02, -dy * base * 0.02, np.ones_like(dx)], axis=-1)
     nrm /= np.linalg.norm(nrm, axis=-1, keepdims=True)
     normal = np.clip((nrm * 0.5 + 0.5) * 255.0, 0, 255).astype(np.uint8)
     gloss = np.clip((0.2 + 0.6 * n2) * 255.0, 0, 255).astype(np.uint8)
-    return albedo, normal, gloss
+    return np.ascontiguousarray(albedo), np.ascontiguousarray(normal), np.ascontiguousarray(gloss)
 
 
 def procedural_hdri(w=4096, h=2048, seed=11):
     """fp32 equirectangular sky standing in for the reference's missing examples/hdris/*.hdr:
     gradient sky + warm ground + a few high-intensity lobes (so the bloom threshold 3.0 triggers)."""
-    x = (np.arange(w) + 0.5) / w
-    y = (np.arange(h) + 0.5) / h
+    x = ((np.arange(w) + 0.5) / w).astype(np.float32)
+    y = ((np.arange(h) + 0.5) / h).astype(np.float32)
     X, Y = np.meshgrid(x, y, indexing="xy")
     sky = np.stack([0.35 + 0.3 * Y, 0.5 + 0.25 * Y, 0.9 - 0.2 * Y], axis=-1)
     ground = np.stack([0.25 + 0 * Y, 0.22 + 0 * Y, 0.2 + 0 * Y], axis=-1)
     k = np.clip((Y - 0.55) / 0.1, 0, 1)[..., None]
     img = sky * (1 - k) + ground * k
-    clouds = fbm(X, Y * 0.5, 5, seed, base=8)[..., None]
+    factor = max(1, w // 512)
+    bw, bh = w // factor, h // factor
+    bx = (np.arange(bw) + 0.5) / bw
+    by = (np.arange(bh) + 0.5) / bh
+    BX, BY = np.meshgrid(bx, by, indexing="xy")
+    clouds = _upsample(fbm(BX, BY * 0.5, 5, seed, base=8), factor)[:h, :w, None]
     img = img * (0.8 + 0.5 * clouds)
     for (cx, cy, rad, inten, col) in [(0.30, 0.22, 0.012, 60.0, (1.0, 0.93, 0.8)), (0.72, 0.30, 0.03, 9.0, (1.0, 0.85, 0.7)),
                                       (0.55, 0.12, 0.02, 14.0, (0.8, 0.9, 1.0))]:
         dxw = np.minimum(np.abs(X - cx), 1 - np.abs(X - cx))
         d2 = (dxw * 2) ** 2 + (Y - cy) ** 2
-        img += (inten * np.exp(-d2 / (2 * rad * rad)))[..., None] * np.asarray(col)
+        img += (inten * np.exp(-d2 / np.float32(2 * rad * rad)))[..., None] * np.asarray(col, dtype=np.float32)
     return np.ascontiguousarray(img.astype(np.float32))
 
 

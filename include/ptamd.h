@@ -1,0 +1,187 @@
+/*
+ * ptamd.h -- C ABI of the MI355X path-tracing library (libptamd.so).
+ *
+ * The reference (henrikglass/cuda-path-tracer) has no FFI layer: its boundary is the host C++
+ * class API that src/main.cu uses, and every class talks to the GPU itself (cudaMalloc /
+ * cudaMemcpy / <<<>>> inside copy_to_device() and Renderer::render).  This header is the seam
+ * that replaces those calls: the C++ facade in cuda-path-tracer_amd/host/ (same class names and
+ * signatures as the reference) and any other binding (ctypes, cgo, JNI ...) call ONLY these
+ * functions.  Plain pointers and sizes; no C++ or torch types.
+ *
+ * Conventions
+ *   - every function returns 0 on success, non-zero on error; pt_last_error() gives the message
+ *     (thread-local).  The C++ facade turns a non-zero status into the reference's
+ *     print-and-exit behaviour (src/util.cuh:7-13).
+ *   - "device pointer" arguments are HIP device addresses on the scene's (or the given) device;
+ *     entry points that say "host or device" accept either and stage host memory themselves.
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream).  Calls enqueue work
+ *     and return; results are complete after the stream is synchronised, except where a function
+ *     writes to a HOST pointer, in which case it synchronises the stream itself before returning.
+ *   - vec3 images are float[H][W][3] (12 bytes per pixel), the layout of the reference's
+ *     std::vector<vec3> image buffers.
+ */
+#ifndef PTAMD_H
+#define PTAMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PT_MAX_OCTREE_DEPTH 12   /* reference: fixed 6 (src/geometry.cuh:4) */
+
+typedef struct pt_scene pt_scene;
+
+/* src/camera.h:6-28 */
+typedef struct {
+    float position[3];
+    float direction[3];
+    float up[3];
+    int   res_x, res_y;
+    float focal_length;
+    float aperture;
+    float focus_distance;
+} pt_camera;
+
+/* src/material.cuh:46-58; maps are host pointers to 8-bit texels (RGB interleaved for the three
+ * colour maps, one channel for smoothness), NULL = not set (src/texture.cuh:12). */
+typedef struct {
+    float albedo[3];
+    float specular[3];
+    float emission;
+    float smoothness;
+    int   smooth_shading;
+    const uint8_t *albedo_map;     int albedo_w, albedo_h;
+    const uint8_t *specular_map;   int specular_w, specular_h;
+    const uint8_t *normal_map;     int normal_w, normal_h;
+    const uint8_t *smoothness_map; int smoothness_w, smoothness_h;
+} pt_material_desc;
+
+/* result of one closest-hit query; replaces the reference's Intersection (src/geometry.cuh:67-77) */
+typedef struct {
+    int32_t entity;      /* index in insertion order, -1 = miss */
+    int32_t triangle;    /* triangle index inside the entity, -1 = sphere or miss */
+    float   t;           /* FLT_MAX on miss */
+    float   bu, bv;      /* raw barycentrics of the accepted triangle test */
+    float   u, v;        /* after uv interpolation (== bu,bv when the mesh has no uvs) */
+    float   position[3];
+    float   normal[3];   /* geometric, or interpolated vertex normal when smooth_shading */
+} pt_hit;
+
+/* work counters, summed over the launch */
+typedef struct {
+    uint64_t segments;     /* trace calls (ray segments) */
+    uint64_t aabb_tests;   /* entity AABB slab tests */
+    uint64_t node_visits;  /* octree nodes entered */
+    uint64_t tri_tests;    /* ray/triangle tests */
+    uint64_t env_lookups;  /* HDRI lookups */
+    uint64_t tex_fetches;  /* texel fetches */
+    uint64_t paths;        /* radiance samples */
+} pt_counters;
+
+/* flattened octree of one mesh entity, read back for structure checks */
+typedef struct {
+    int32_t  max_depth;
+    int64_t  n_nodes;
+    int64_t  n_leaf_refs;
+    int64_t  max_leaf;
+    int64_t  nodes_per_depth[PT_MAX_OCTREE_DEPTH + 1];
+} pt_octree_info;
+
+const char *pt_last_error(void);
+/* replaces cudaGetDevice/cudaGetDeviceProperties in Renderer::render (src/renderer.cu:209-216) */
+int pt_device_count(int *count);
+int pt_device_name(int device, char *buf, size_t cap);
+
+/* ---- scene: replaces Scene/Entity/Material/Texture/Octree::copy_to_device + free_from_device
+ *      (src/scene.cu:67-110, src/entity.cu:263-337, src/octree.cu:24-61, src/material.cu:32-60,
+ *      src/texture.cu:19-49, external/hdrloader.h:30-41). */
+/* device < 0 creates a host-only scene: meshes and octrees can be built and inspected, commit fails */
+int pt_scene_create(int device, pt_scene **out);
+int pt_scene_destroy(pt_scene *scene);
+int pt_scene_add_material(pt_scene *scene, const pt_material_desc *desc, int *material_out);
+/* positions/normals: n_vertices x 3 floats (normals NULL -> area-unweighted face-normal average,
+ * src/entity.cu:110-133); tri: n_triangles x 6 ints (vertex a,b,c, uv a,b,c; uv indices ignored
+ * when n_uvs == 0); octree_depth 0 = no octree (brute force, src/device_geometry_functions.cuh:
+ * 286-291), otherwise the leaf depth of the octree built as Entity::construct_octree does
+ * (src/entity.cu:167-170, src/octree.cu:83-142; the reference uses 6). */
+int pt_scene_add_mesh(pt_scene *scene, const float *positions, const float *normals, int n_vertices,
+                      const int32_t *tri, int n_triangles, const float *uvs, int n_uvs,
+                      int material, int octree_depth, int *entity_out);
+int pt_scene_add_sphere(pt_scene *scene, const float center[3], float radius, int material,
+                        int *entity_out);
+/* rgb: h x w x 3 floats, row 0 first (src/scene.cu:19-55) */
+int pt_scene_set_hdri(pt_scene *scene, const float *rgb, int w, int h, float exposure,
+                      float contrast, float rot_offset, int smooth);
+/* flattens every octree into the linear node / triangle-record arrays and uploads the scene */
+int pt_scene_commit(pt_scene *scene);
+int pt_scene_octree_info(pt_scene *scene, int entity, pt_octree_info *info);
+/* canonical pre-order dump of the flattened octree: per node {depth, slot, child mask, n_tris,
+ * tris...}; returns the number of int32 words needed in *n_words (out may be NULL). */
+int pt_scene_octree_dump(pt_scene *scene, int entity, int32_t *out, int64_t cap, int64_t *n_words);
+/* bytes of device memory the committed scene occupies, by array */
+int pt_scene_device_bytes(pt_scene *scene, uint64_t *nodes, uint64_t *tri_records,
+                          uint64_t *shade_records, uint64_t *textures, uint64_t *hdri);
+
+/* ---- geometry: the closest-hit query of trace() (src/device_geometry_functions.cuh:201-234).
+ * rays: n x 6 floats (origin, direction), host or device.  hits: n records, host or device.
+ * log (optional, host or device): n x log_stride ints, [0] = number of triangle tests of that ray,
+ * then the tested triangle ids in order (truncated to log_stride-1).  counters: host, optional. */
+int pt_trace_rays(pt_scene *scene, const float *rays, int64_t n, pt_hit *hits, int32_t *log,
+                  int log_stride, pt_counters *counters, void *stream);
+/* primary rays of sample `sample` for every pixel (src/renderer.cu:60-87), n = W*H rays x 6
+ * floats to a host or device buffer; for parity tests of the ray generator. */
+int pt_camera_rays(int device, const pt_camera *camera, uint32_t seed, int sample, float *rays,
+                   void *stream);
+
+/* ---- render: replaces render_init + device_render (src/renderer.cu:19-51, 233-257).
+ * Adds, for every pixel, the radiance samples sample_begin..sample_end-1 into n_split split
+ * buffers: d_split is a DEVICE pointer to n_split x H x W x 3 floats (src/renderer.cu:194-197);
+ * split buffer z receives the samples of the z-th of n_split equal sub-ranges.  += semantics: the
+ * caller zeroes the buffers before the first call.  Sample s of pixel p draws from the Philox
+ * stream (seed; p, s), so the image does not depend on how samples are sharded over calls/GPUs
+ * beyond floating-point summation order.  counters: host pointer, optional (forces a stream sync). */
+int pt_render_accumulate(pt_scene *scene, const pt_camera *camera, uint32_t seed,
+                         int sample_begin, int sample_end, int n_split, float *d_split,
+                         pt_counters *counters, void *stream);
+/* Measurement aid (no counterpart in the reference): when enabled, every pt_render_accumulate
+ * brackets its path-tracing kernel with two HIP events on the launch stream;
+ * pt_scene_last_render_kernel_ms waits for the last launch and returns its duration. */
+int pt_scene_set_profiling(pt_scene *scene, int enable);
+int pt_scene_last_render_kernel_ms(pt_scene *scene, float *ms);
+/* d_out[p] = sum_z d_split[z][p]  (compound_buffers, src/post_processing.cu:243-256); device ptrs */
+int pt_compound_buffers(int device, const float *d_split, float *d_out, int64_t n_pixels,
+                        int n_split, void *stream);
+
+/* ---- post-processing: replaces apply_filter/device_apply_filter and the CPU loops
+ *      (src/post_processing.cu:105-187, 194-278).  All image pointers are DEVICE pointers. */
+/* taps: (2*ksize+1)^2 floats, host pointer (Kernel::make_gaussian / make_mean tables);
+ * filter_type 0 = NORMAL, 1 = BILATERAL (src/post_processing.cuh:26-29) */
+int pt_apply_filter(int device, const float *d_in, float *d_out, int w, int h, const float *taps,
+                    int ksize, int filter_type, void *stream);
+int pt_make_gaussian(unsigned size, float sigma, float *taps_out);   /* host, src/post_processing.cu:51-68 */
+int pt_make_mean(unsigned size, float *taps_out);                    /* host, src/post_processing.cu:73-84 */
+int pt_normalize_image(int device, float *d_buf, int64_t n_pixels, unsigned n_samples, void *stream);
+int pt_apply_threshold(int device, const float *d_in, float *d_out, int64_t n_pixels, float threshold, void *stream);
+int pt_image_add(int device, float *d_buf, const float *d_layer, int64_t n_pixels, float opacity, void *stream);
+int pt_apply_aces(int device, float *d_buf, int64_t n_pixels, void *stream);
+int pt_gamma_correct(int device, float *d_buf, int64_t n_pixels, float gamma, void *stream);
+/* the fixed chain of Renderer::render (src/renderer.cu:277-297) run device-resident:
+ * d_sum (un-normalised radiance sums, H x W x 3) -> d_out (tone-mapped LDR); d_sum is not modified */
+int pt_post_chain(int device, const float *d_sum, float *d_out, int w, int h, unsigned n_samples,
+                  void *stream);
+
+/* plain device-memory helpers so that a host facade needs no HIP headers */
+int pt_malloc(int device, size_t bytes, void **d_ptr);
+int pt_free(int device, void *d_ptr);
+int pt_memset(int device, void *d_ptr, int value, size_t bytes, void *stream);
+int pt_upload(int device, void *d_dst, const void *h_src, size_t bytes, void *stream);
+int pt_download(int device, void *h_dst, const void *d_src, size_t bytes, void *stream);
+int pt_stream_synchronize(int device, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

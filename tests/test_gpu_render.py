@@ -1,0 +1,111 @@
+"""GPU tests of the render path (pt_render_accumulate through the C ABI) against the CPU oracle.
+
+Shaded images cannot be bit-exact: the reference is not reproducible against itself (it races on
+its RNG state and accumulation buffer), and the HIP kernel uses the hardware exp/log/sin/cos units
+where the oracle uses libm.  Both sides draw the SAME Philox numbers per (pixel, sample, bounce), so
+at equal spp the two images differ only where a last-bit difference flipped a discrete decision.
+Tolerances (linear HDR radiance, un-post-processed):
+  * equal spp:   relative RMSE(GPU, oracle) <= 2 % of the image's RMS, and <= 25 % of the Monte-Carlo
+                 noise RMSE(oracle @ spp, oracle @ 16 x spp);
+  * convergence: RMSE(GPU @ spp, converged oracle) within 15 % of RMSE(oracle @ spp, converged oracle).
+Work counters (paths, segments) must agree within 0.5 %.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _rmse(a, b):
+    return float(np.sqrt(np.mean((a.astype(np.float64) - b.astype(np.float64)) ** 2)))
+
+
+def _pair(pt, oracle, scenes, desc):
+    g, cam_g = pt.scene_from_description(desc)
+    c, cam_c = scenes.build_oracle_scene(desc, oracle)
+    return g, cam_g, c, cam_c
+
+
+@pytest.mark.parametrize("name", ["cornellbox", "teapot", "hcandersen"])
+def test_render_matches_oracle(pt, oracle, scenes, name):
+    if name == "cornellbox":
+        desc, spp = scenes.cornellbox_scene(res=(96, 56)), 32
+    elif name == "teapot":
+        desc, spp = scenes.teapot_scene(res=(96, 56)), 32
+    else:
+        desc, spp = scenes.hcandersen_scene(res=(96, 56), n_tris=8000, tex_res=256, hdri_res=(512, 256)), 32
+    g, cam_g, c, cam_c = _pair(pt, oracle, scenes, desc)
+    img_g, cnt_g = pt.render_image(g, cam_g, spp, seed=1337, n_split=4, want_counters=True)
+    img_c, cnt_c = c.render(cam_c, 1337, 0, spp, n_threads=8)
+    img_g /= spp
+    img_c /= spp
+    assert np.isfinite(img_g).all()
+    rms = float(np.sqrt(np.mean(img_c.astype(np.float64) ** 2)))
+    assert rms > 0
+    err = _rmse(img_g, img_c)
+    conv, _ = c.render(cam_c, 1337, 1000, 1000 + 16 * spp, n_threads=8)
+    conv /= 16 * spp
+    noise_c = _rmse(img_c, conv)
+    noise_g = _rmse(img_g, conv)
+    assert err <= 0.02 * rms, (err, rms)
+    assert err <= 0.25 * noise_c, (err, noise_c)
+    assert abs(noise_g - noise_c) <= 0.15 * noise_c, (noise_g, noise_c)
+    assert cnt_g["paths"] == cnt_c["paths"] == 96 * 56 * spp
+    for k in ("segments", "tri_tests", "node_visits", "env_lookups", "tex_fetches"):
+        assert abs(cnt_g[k] - cnt_c[k]) <= 0.005 * max(cnt_c[k], 1) + 2, (k, cnt_g[k], cnt_c[k])
+    g.close()
+
+
+def test_render_is_reproducible_and_shardable(pt, scenes):
+    """Same call twice -> identical bits (no atomics on pixels, fixed summation order); the sample
+    range split over two calls, or rendered as two 'ranks' and summed, gives the same image up to
+    fp32 association; split buffers hold disjoint sample sub-ranges."""
+    desc = scenes.teapot_scene(res=(64, 40))
+    g, cam = pt.scene_from_description(desc)
+    a = pt.render_image(g, cam, 64, seed=7, n_split=4)
+    b = pt.render_image(g, cam, 64, seed=7, n_split=4)
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    lo = pt.render_image(g, cam, 32, seed=7, n_split=4, sample_begin=0)
+    hi = pt.render_image(g, cam, 32, seed=7, n_split=4, sample_begin=32)
+    assert np.allclose(lo + hi, a, rtol=2e-5, atol=1e-5)
+    one = pt.render_image(g, cam, 64, seed=7, n_split=1)
+    assert np.allclose(one, a, rtol=2e-5, atol=1e-5)
+    other_seed = pt.render_image(g, cam, 64, seed=8, n_split=4)
+    assert not np.array_equal(a, other_seed)
+    # += semantics and per-split sample ranges: split z of a 4-way render == 1-way render of its quarter
+    n_pixels = cam.res_x * cam.res_y
+    split = pt.DeviceBuffer(0, 4 * n_pixels * 12)
+    split.zero()
+    g.render_accumulate(cam, 7, 0, 64, 4, split.ptr)
+    s = split.download((4, cam.res_y, cam.res_x, 3))
+    q2 = pt.render_image(g, cam, 16, seed=7, n_split=1, sample_begin=32)
+    assert np.array_equal(s[2].view(np.uint32), q2.view(np.uint32))
+    g.render_accumulate(cam, 7, 0, 64, 4, split.ptr)          # accumulate the same samples again
+    s2 = split.download((4, cam.res_y, cam.res_x, 3))
+    assert np.allclose(s2, 2 * s, rtol=1e-6, atol=1e-7)
+    g.close()
+
+
+def test_render_edge_cases(pt, scenes):
+    desc = scenes.cornellbox_scene(res=(40, 24))
+    g, cam = pt.scene_from_description(desc)
+    n_pixels = cam.res_x * cam.res_y
+    split = pt.DeviceBuffer(0, 4 * n_pixels * 12)
+    split.zero()
+    g.render_accumulate(cam, 1, 5, 5, 4, split.ptr)            # empty sample range: no-op
+    assert not split.download((4 * n_pixels * 3,)).any()
+    g.render_accumulate(cam, 1, 0, 3, 4, split.ptr)            # fewer samples than split buffers
+    s = split.download((4, n_pixels, 3))
+    assert s.sum() > 0 and np.isfinite(s).all()
+    with pytest.raises(pt.PtError, match="n_split"):
+        g.render_accumulate(cam, 1, 0, 4, 0, split.ptr)
+    with pytest.raises(pt.PtError, match="sample range"):
+        g.render_accumulate(cam, 1, 4, 2, 4, split.ptr)
+    # resolution not divisible by the 8x8 work tile: every pixel is still rendered
+    desc = scenes.cornellbox_scene(res=(37, 21))
+    g2, cam2 = pt.scene_from_description(desc)
+    img, cnt = pt.render_image(g2, cam2, 8, want_counters=True)
+    assert cnt["paths"] == 37 * 21 * 8
+    assert (img.sum(axis=-1) > 0).mean() > 0.5
+    g.close()
+    g2.close()
