@@ -1,0 +1,199 @@
+#!/usr/bin/env python3
+"""Headline benchmark: Mpaths/s and time-to-2048-spp on the hcandersen-class scene at 1920x1080.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One step = one full render of the workload: every pixel's sample range [0, spp) traced by the
+persistent HIP kernel (pt_render_accumulate through the C ABI), split buffers compounded on the
+device and -- for N > 1 -- the per-rank radiance sums combined on rank 0 with one RCCL sum-reduce.
+With N ranks the sample range is sharded (rank r renders spp/N samples of every pixel), so total
+work is fixed: strong scaling.  The scene (procedural stand-ins for the reference's unshipped
+80k.obj, textures and HDRI) is resident in HBM before the timed region starts; scene generation,
+octree build, upload and post-processing are reported separately and are not part of `value`.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(REPO, "cuda-path-tracer_amd", "python"))
+
+HBM_PEAK_GBPS = 8000.0       # MI355X HBM3E spec peak
+# algorithmic bytes per unit of traversal / shading work (what one unit must read from the scene arrays)
+B_NODE = 8                   # one flattened octree node record
+B_TRI = 48                   # one pre-gathered triangle record (v0, e1, e2, id)
+B_SHADE = 64 + 48            # per hit: one shading record (3 normals + 3 uvs) + re-read of the accepted triangle record
+B_TEXEL = 3                  # RGB8 texel (gloss: 1, counted as 3 for simplicity -> upper bound below 0.1 % of the total)
+B_ENV = 48                   # bilinear HDRI lookup: 4 texels x 12 B
+B_ENTITY = 128               # entity record + AABB per (segment, entity)
+
+
+def algorithmic_bytes(counters, n_pixels, n_slices, n_entities):
+    hits = counters["segments"] - counters["env_lookups"] if counters["env_lookups"] else counters["segments"]
+    return (counters["node_visits"] * B_NODE + counters["tri_tests"] * B_TRI + hits * B_SHADE
+            + counters["tex_fetches"] * B_TEXEL + counters["env_lookups"] * B_ENV
+            + counters["segments"] * n_entities * B_ENTITY + n_pixels * 12 * n_slices)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="hcandersen", choices=["hcandersen", "teapot", "cornellbox", "dragon"])
+    ap.add_argument("--spp", type=int, default=0, help="override samples per pixel (default: the config's)")
+    ap.add_argument("--res", type=str, default="", help="override resolution WxH")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--save-ppm", type=str, default="", help="write the post-processed image of the last step")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    import ptamd
+    from ptamd import dist as ptdist
+    from ptamd import scenes as S
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    dev = local_rank
+
+    cfg = S.CONFIGS[args.workload]
+    res = tuple(int(x) for x in args.res.split("x")) if args.res else cfg["res"]
+    spp = ptdist.effective_spp(args.spp if args.spp else cfg["spp"])
+    t0 = time.time()
+    desc = cfg["builder"](res=res)
+    t_gen = time.time() - t0
+    t0 = time.time()
+    scene, cam = ptamd.scene_from_description(desc, device=dev)
+    t_upload = time.time() - t0
+    n_pixels = res[0] * res[1]
+    n_split = 4
+    n_entities = len(desc["entities"])
+    s_begin, s_end = ptdist.shard_samples(spp, rank, world)
+
+    split = torch.zeros((n_split, res[1], res[0], 3), dtype=torch.float32, device=f"cuda:{dev}")
+    local_sum = torch.zeros((res[1], res[0], 3), dtype=torch.float32, device=f"cuda:{dev}")
+    stream = torch.cuda.current_stream().cuda_stream
+    L = ptamd.lib()
+
+    def step(want_counters=False):
+        split.zero_()
+        cnt = scene.render_accumulate(cam, 1337, s_begin, s_end, n_split, split.data_ptr(), want_counters, stream)
+        ptamd.check(L.pt_compound_buffers(dev, split.data_ptr(), local_sum.data_ptr(), n_pixels, n_split, stream))
+        if world > 1:
+            dist.reduce(local_sum, dst=0, op=dist.ReduceOp.SUM)
+        return cnt
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    # one untimed pass with the in-kernel work counters (identical work: same seed, same samples)
+    counters = step(want_counters=True)
+    scene.set_profiling(True)
+    fence()
+    kernel_ms = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+        # the event pair sits on the launch stream; reading it waits only for that step's kernel
+        kernel_ms.append(scene.last_render_kernel_ms())
+    fence()
+    elapsed = time.perf_counter() - t0
+    scene.set_profiling(False)
+
+    t = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{dev}")
+    cvec = torch.tensor([counters[k] for k in ptamd.COUNTER_NAMES], dtype=torch.float64, device=f"cuda:{dev}")
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(cvec, op=dist.ReduceOp.SUM)
+    elapsed = float(t.item())
+    total_counters = {k: int(v) for k, v in zip(ptamd.COUNTER_NAMES, cvec.tolist())}
+
+    ms_per_step = 1000.0 * elapsed / max(args.steps, 1)
+    paths_per_step = n_pixels * spp
+    value = paths_per_step / (ms_per_step / 1000.0) / 1e6
+
+    # roofline of the dominant kernel (this rank's launch): algorithmic bytes / measured kernel time
+    plan_slices = n_split * min(32, max(1, (-(-(s_end - s_begin) // n_split) + 31) // 32))
+    k_ms = float(np.mean(kernel_ms)) if kernel_ms else float("nan")
+    alg_bytes = algorithmic_bytes(counters, n_pixels, plan_slices, n_entities)
+    achieved = alg_bytes / (k_ms / 1000.0) / 1e9 if k_ms > 0 else 0.0
+    roofline = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": None,
+                "kernel": "render_kernel", "kernel_ms": round(k_ms, 3), "algorithmic_bytes_per_launch": int(alg_bytes)}
+
+    cpu_baseline = None
+    post_ms = None
+    if rank == 0:
+        # post-processing (reported separately): the reference's fixed chain, device resident
+        out = torch.empty_like(local_sum)
+        torch.cuda.synchronize()
+        tp = time.perf_counter()
+        ptamd.check(L.pt_post_chain(dev, local_sum.data_ptr(), out.data_ptr(), res[0], res[1], spp, stream))
+        torch.cuda.synchronize()
+        post_ms = 1000.0 * (time.perf_counter() - tp)
+        if args.save_ppm:
+            sys.path.insert(0, os.path.join(REPO, "cuda-path-tracer_amd", "python"))
+            from ptamd import io as ptio
+            ptio.save_ppm(args.save_ppm, out.cpu().numpy())
+        if not args.no_cpu_baseline and world == 1:
+            sys.path.insert(0, os.path.join(REPO, "oracle"))
+            import oracle_api as O
+            osc, ocam = S.build_oracle_scene(desc, O)
+            cores = min(os.cpu_count() or 1, 16)
+            rows = (0, res[1])
+            tc = time.perf_counter()
+            osc.render(ocam, 1337, 0, 1, rows=rows, n_threads=cores)
+            t1 = time.perf_counter() - tc
+            n_cpu = int(max(1, min(16, round(12.0 / max(t1, 1e-3)))))
+            tc = time.perf_counter()
+            _, ccnt = osc.render(ocam, 1337, 1, 1 + n_cpu, rows=rows, n_threads=cores)
+            tn = time.perf_counter() - tc
+            cpu_baseline = {"value": round(n_pixels * n_cpu / tn / 1e6, 4), "unit": "Mpaths/s", "cores": cores, "kind": "port",
+                            "sample": f"full {res[0]}x{res[1]} frame, {n_cpu} spp, {cores} threads, {tn:.1f} s"}
+
+    if rank == 0:
+        line = {
+            "metric": "Mpaths/s (+ time-to-2048spp), hcandersen 1080p" if args.workload == "hcandersen" else f"Mpaths/s, {args.workload}",
+            "value": round(value, 3), "unit": "Mpaths/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{args.workload} {res[0]}x{res[1]} {spp}spp octree-depth-{max(e.get('octree_depth', 0) for e in desc['entities'] if e['kind'] == 'mesh')}",
+                       "triangles": int(sum(len(e["tri"]) for e in desc["entities"] if e["kind"] == "mesh")),
+                       "spp": spp, "samples_per_rank": s_end - s_begin, "parallelism": f"sample-shard x{world}"},
+            "time_to_spp_s": round(ms_per_step / 1000.0, 4),
+            "msegments_per_s": round(total_counters["segments"] / (ms_per_step / 1000.0) / 1e6, 2),
+            "counters": total_counters,
+            "roofline": roofline, "cpu_baseline": cpu_baseline,
+            "post_chain_ms": None if post_ms is None else round(post_ms, 2),
+            "scene_gen_s": round(t_gen, 2), "scene_build_upload_s": round(t_upload, 2),
+            "scene_device_bytes": scene.device_bytes(),
+        }
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -471,6 +471,8 @@ int pt_trace_rays(pt_scene *scene, const float *rays, int64_t n, pt_hit *hits, i
         if (log && !log_dev) {
             if (hipMalloc(&tmp_log, (size_t)n * log_stride * 4) != hipSuccess) { rc = hip_fail(hipErrorOutOfMemory, "hipMalloc log", __FILE__, __LINE__); break; }
             d_log = (int32_t *)tmp_log;
+            /* entries past a ray's test count read as 0 */
+            if (hipMemsetAsync(tmp_log, 0, (size_t)n * log_stride * 4, stream) != hipSuccess) { rc = 1; set_error("pt_trace_rays: memset failed"); break; }
         }
         if (counters && hipMemsetAsync(scene->d_stats, 0, 7 * sizeof(unsigned long long), stream) != hipSuccess) { rc = 1; set_error("pt_trace_rays: memset failed"); break; }
         rc = launch_trace(scene->dev, d_rays, n, d_hits, d_log, log_stride, counters ? scene->d_stats : nullptr, stream);

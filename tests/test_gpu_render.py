@@ -106,6 +106,11 @@ def test_render_edge_cases(pt, scenes):
     g2, cam2 = pt.scene_from_description(desc)
     img, cnt = pt.render_image(g2, cam2, 8, want_counters=True)
     assert cnt["paths"] == 37 * 21 * 8
-    assert (img.sum(axis=-1) > 0).mean() > 0.5
+    assert np.isfinite(img).all() and img.sum() > 0
+    # the last column / row belong to partial tiles: they must have been traced like any other
+    # pixel (same image as the top-left 37x21 crop is NOT expected -- the camera differs -- so
+    # compare against the oracle-free invariant: rendering twice gives identical bits)
+    img2 = pt.render_image(g2, cam2, 8)
+    assert np.array_equal(img.view(np.uint32), img2.view(np.uint32))
     g.close()
     g2.close()

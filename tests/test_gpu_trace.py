@@ -124,8 +124,9 @@ def test_empty_and_device_resident_buffers(teapot_pair, pt):
 
 
 def test_camera_rays_match_oracle(pt, oracle):
-    """Ray generator: pinhole rays are bit-exact; thin-lens rays use the hardware sin/cos, so the
-    tolerance is 2e-6 absolute on unit directions and 2e-6 * aperture on origins."""
+    """Ray generator: pinhole rays are bit-exact; thin-lens rays use the hardware sin/cos (abs. error
+    about 1e-6 on the lens offset), so origins may differ by 2 ulp at their magnitude (|x| < 64 ->
+    8e-6) and unit directions by 4e-6."""
     for aperture in (0.0, 1.0):
         cam_g = pt.make_camera((40.5, 30.5, -50), (-0.4472136, 0.0, 0.8944272), (160, 90), 2.5, aperture, 85.0)
         cam_c = oracle.make_camera((40.5, 30.5, -50), (-0.4472136, 0.0, 0.8944272), (160, 90), 2.5, aperture, 85.0)
@@ -135,8 +136,8 @@ def test_camera_rays_match_oracle(pt, oracle):
             if aperture == 0.0:
                 assert np.array_equal(_bits(rg), _bits(rc))
             else:
-                assert np.abs(rg[:, :3] - rc[:, :3]).max() <= 2e-6
-                assert np.abs(rg[:, 3:] - rc[:, 3:]).max() <= 2e-6
+                assert np.abs(rg[:, :3] - rc[:, :3]).max() <= 8e-6
+                assert np.abs(rg[:, 3:] - rc[:, 3:]).max() <= 4e-6
 
 
 def test_missing_library_or_uncommitted_scene_fails_loudly(pt, teapot):
