@@ -5,12 +5,22 @@
  * IEEE fp32 in source order -- the translation unit is built with -ffp-contract=off and HIP's
  * default correctly rounded divide / sqrt -- so hit ids, distances, barycentrics and the order of
  * triangle tests are bit-identical to a scalar CPU evaluation of the same formulas.  Shading may
- * contract and uses the hardware transcendental units, like the reference's -use_fast_math build.
+ * use the hardware transcendental units, like the reference's -use_fast_math build.
  *
  * Reference functions restated here (src/device_geometry_functions.cuh = dgf):
  *   intersects_aabb dgf:388-417, intersect_triangle dgf:319-365, sphere dgf:257-275,
- *   Octree::ray_step dgf:39-89, proc_subtree/find_first_node/next_node dgf:95-191 (made
- *   iterative), trace dgf:201-234, Ray::recalc_fracs src/geometry.cuh:23-28.
+ *   Octree::ray_step dgf:39-89, proc_subtree/find_first_node/next_node dgf:95-191,
+ *   trace dgf:201-234, Ray::recalc_fracs src/geometry.cuh:23-28.
+ *
+ * Execution model.  The reference runs trace() as one recursive call chain per thread; on a 64-wide
+ * wave that leaves most lanes idle (one lane in a 30-triangle leaf stalls 63 others).  Here every
+ * lane carries its ray through an explicit state machine
+ *     ENTITY -> (NODE <-> LEAF)* -> ENTITY ... -> DONE
+ * and the wave repeatedly runs the block (entity set-up, octree node step, triangle test) that the
+ * most lanes are waiting for.  One trip of a block is the same short instruction sequence for all
+ * participating lanes, so divergence is bounded by the mix of states, not by the shape of each
+ * lane's recursion.  The recursion's frames live in a per-lane stack of one 16-byte word per level
+ * in LDS plus three bits per level in a register.
  */
 #ifndef PT_DEVICE_H
 #define PT_DEVICE_H
@@ -63,37 +73,53 @@ struct TriLog {        /* optional per-ray record of the triangle-test sequence 
     int32_t cap;
 };
 
-/* dgf:319-365 on a pre-gathered record; e1,e2 were formed on the host by the same fp32
- * subtractions the reference performs per test. */
-template <bool LOG>
-__device__ __forceinline__ bool intersect_record(const PtTriRec *__restrict__ recs, uint32_t idx, V3 o, V3 d,
-                                                 Best &best, int32_t entity, Stats &st, TriLog &lg) {
-    const float4 *q = reinterpret_cast<const float4 *>(recs + idx);
-    const float4 r0 = q[0], r1 = q[1], r2 = q[2];
-    st.tri_tests++;
-    const int32_t id = __float_as_int(r2.y);
-    if (LOG) {
-        int n = lg.p[0]++;
-        if (n + 1 < lg.cap) lg.p[n + 1] = id;
+enum : int { M_ENTITY = 0, M_NODE = 1, M_LEAF = 2, M_DONE = 3, M_IDLE = 4 };
+
+/* per-lane state of the ray being traced */
+struct Lane {
+    V3 o, d;                 /* the ray (triangle and sphere tests always use the original ray) */
+    Best best;
+    int32_t mode;
+    int32_t ent;             /* entity being processed (M_ENTITY: about to start it) */
+    /* octree walk */
+    float t0x, t0y, t0z, t1x, t1y, t1z;   /* parametric interval of the current node */
+    uint32_t nb, nm;         /* current node: index of first child, child mask */
+    uint32_t nbase;          /* entity's first node (stack words hold child indices relative to it) */
+    uint32_t path;           /* 3 bits per level: the child slot taken at each ancestor */
+    int32_t curr;            /* next child candidate (mirrored numbering), 8 = node exhausted */
+    int32_t level, maxd, a;
+    /* triangle run (octree leaf or brute-force mesh) */
+    uint32_t tri_cur, tri_end;
+    int32_t run_flags;       /* bit0: some test of this run was accepted, bit1: run is an octree leaf */
+};
+
+/* dgf:116-126 with the per-child argument table of dgf:178-187 folded in: the exit parameters of
+ * child `curr` are that child's t1, and the successor along an axis is curr with that axis bit
+ * set, or 8 (leave the node) when the bit is already set. */
+__device__ __forceinline__ int next_child(int curr, float ex, float ey, float ez) {
+    const int cx = (curr & 4) ? 8 : (curr | 4);
+    const int cy = (curr & 2) ? 8 : (curr | 2);
+    const int cz = (curr & 1) ? 8 : (curr | 1);
+    int r = cz;
+    if (ex < ey) {
+        if (ex < ez) r = cx;
+    } else {
+        if (ey < ez) r = cy;
     }
-    const V3 v0 = mk(r0.x, r0.y, r0.z), e1 = mk(r0.w, r1.x, r1.y), e2 = mk(r1.z, r1.w, r2.x);
-    const V3 pvec = cross3(d, e2);
-    const float det = dot3(e1, pvec);
-    if (fabsf(det) < 0.000000001f) return false;
-    const float inv_det = 1.0f / det;
-    const V3 tvec = o - v0;
-    const float u = dot3(tvec, pvec) * inv_det;
-    if (u < -0.0001f || u > 1.0001f) return false;
-    const V3 qvec = cross3(tvec, e1);
-    const float v = dot3(d, qvec) * inv_det;
-    if (v < -0.0001f || u + v > 1.0001f) return false;
-    const float t = dot3(e2, qvec) * inv_det;
-    if (t > 0 && t < best.t) {
-        best.t = t; best.bu = u; best.bv = v;
-        best.entity = entity; best.tri = id; best.rec = idx;
-        return true;
+    return r;
+}
+
+/* dgf:95-110 */
+__device__ __forceinline__ int first_child(float t0x, float t0y, float t0z, float tMx, float tMy, float tMz) {
+    int answer;
+    if (t0x > t0y && t0x > t0z) {
+        answer = ((tMy < t0x) ? 2 : 0) | ((tMz < t0x) ? 1 : 0);
+    } else if (t0y > t0z) {
+        answer = ((tMx < t0y) ? 4 : 0) | ((tMz < t0y) ? 1 : 0);
+    } else {
+        answer = ((tMx < t0z) ? 4 : 0) | ((tMy < t0z) ? 2 : 0);
     }
-    return false;
+    return answer;
 }
 
 /* dgf:388-417 */
@@ -109,53 +135,51 @@ __device__ __forceinline__ bool slab_test(const float mn[3], const float mx[3], 
     return !(tmax < 0.0f || tmin > tmax || best_t < tmin);
 }
 
-/* dgf:116-126 with the per-child argument table of dgf:178-187 folded in: the exit parameters of
- * child `curr` are that child's t1, and the successor along an axis is curr with that axis bit
- * set, or 8 (leave the node) when the bit is already set. */
-__device__ __forceinline__ int next_child(int curr, float ex, float ey, float ez) {
-    const int cx = (curr & 4) ? 8 : (curr | 4);
-    const int cy = (curr & 2) ? 8 : (curr | 2);
-    const int cz = (curr & 1) ? 8 : (curr | 1);
-    if (ex < ey) {
-        if (ex < ez) return cx;
-    } else {
-        if (ey < ez) return cy;
-    }
-    return cz;
-}
-
-/* dgf:95-110 */
-__device__ __forceinline__ int first_child(float t0x, float t0y, float t0z, float tMx, float tMy, float tMz) {
-    int answer = 0;
-    if (t0x > t0y && t0x > t0z) {
-        if (tMy < t0x) answer |= 2;
-        if (tMz < t0x) answer |= 1;
-        return answer;
-    } else if (t0y > t0z) {
-        if (tMx < t0y) answer |= 4;
-        if (tMz < t0y) answer |= 1;
-        return answer;
-    }
-    if (tMx < t0z) answer |= 4;
-    if (tMy < t0z) answer |= 2;
-    return answer;
+__device__ __forceinline__ void lane_start_ray(Lane &L, V3 o, V3 d) {
+    L.o = o; L.d = d;
+    L.best.t = FLT_MAX; L.best.bu = 0.f; L.best.bv = 0.f; L.best.entity = -1; L.best.tri = -1; L.best.rec = 0;
+    L.ent = 0;
+    L.mode = M_ENTITY;
 }
 
 /*
- * Octree::ray_step + proc_subtree (dgf:39-191), iterative.  The recursion's frames live in a
- * per-lane stack of one 16-byte word per level in LDS: when descending, each axis of the child
- * interval inherits one bound from the parent ([t0,tM] or [tM,t1]); the word stores the three
- * bounds the child does NOT inherit plus {parent node, child slot}.  On return the parent's
- * t0/tM/t1 are rebuilt from the child's interval and the saved bounds by copies only, so every
- * value is the one the recursion would hold.  Reproduced quirks: the rejection tests t1.y twice
- * and never t1.z (dgf:142); the walk ends at the first leaf that reports an accepted test
- * (dgf:188 unwinds every level once `hit` is set).
+ * ENTITY block: starts processing entity L.ent (trace()'s loop body, dgf:204-206, 241-299).
+ * Spheres are tested in place; a mesh passes the AABB gate and then either becomes a triangle run
+ * over all its records (no octree) or an octree walk whose root has been entered (ray_step,
+ * dgf:39-89: mirror the ray about the octree centre per negative direction component, root
+ * interval, entry test).
  */
-template <bool LOG>
-__device__ __forceinline__ bool octree_traverse(const PtNode *__restrict__ nodes, const PtTriRec *__restrict__ tris,
-                                                const PtEntity &e, int32_t entity, V3 ro, V3 rd, Best &best,
-                                                Stats &st, TriLog &lg, float4 *stack, int stride) {
-    V3 o = ro, d = rd;
+template <bool STATS>
+__device__ __forceinline__ void entity_block(const PtSceneDev &sc, Lane &L, Stats &st) {
+    if (L.ent >= sc.n_entities) { L.mode = M_DONE; return; }
+    const PtEntity &e = sc.entities[L.ent];
+    const int32_t ei = L.ent;
+    L.ent = ei + 1;                       /* default: move on to the next entity */
+    if (e.shape == PT_SHAPE_SPHERE) {     /* dgf:257-275; a sphere hit clears the triangle */
+        const V3 dd = L.o - mk(e.center[0], e.center[1], e.center[2]);
+        const float p1 = -dot3(L.d, dd);
+        const float p2sqr = ((p1 * p1) - dot3(dd, dd)) + (e.radius * e.radius);
+        if (!(p2sqr < 0)) {
+            const float p2 = 1.0f / rsqrt_ieee(p2sqr);
+            const float t = p1 - p2 > 0 ? p1 - p2 : p1 + p2;
+            if (t > 0 && t < L.best.t) {
+                L.best.t = t; L.best.bu = 0.0f; L.best.bv = 0.0f;
+                L.best.entity = ei; L.best.tri = -1; L.best.rec = 0;
+            }
+        }
+        return;
+    }
+    if (STATS) st.aabb_tests++;
+    const V3 fr = mk(clamp_frac(L.d.x), clamp_frac(L.d.y), clamp_frac(L.d.z));
+    if (!slab_test(e.aabb_min, e.aabb_max, L.o, fr, L.best.t)) return;
+    if (e.octree_depth == 0) {            /* dgf:286-291 */
+        if (e.n_tris == 0) return;
+        L.tri_cur = e.tri_first; L.tri_end = e.tri_first + e.n_tris;
+        L.run_flags = 0;
+        L.mode = M_LEAF;
+        return;
+    }
+    V3 o = L.o, d = L.d;
     const float midx = 0.5f * (e.region_max[0] + e.region_min[0]);
     const float midy = 0.5f * (e.region_max[1] + e.region_min[1]);
     const float midz = 0.5f * (e.region_max[2] + e.region_min[2]);
@@ -165,128 +189,179 @@ __device__ __forceinline__ bool octree_traverse(const PtNode *__restrict__ nodes
     if (d.z < 0.0f) { float delta = o.z - midz; o.z = midz - delta; d.z = -d.z; a |= 1; }
     /* fracs of the mirrored ray; for un-mirrored components this is the value the original ray holds */
     const float frx = clamp_frac(d.x), fry = clamp_frac(d.y), frz = clamp_frac(d.z);
-
-    float t0x = (e.region_min[0] - o.x) * frx, t1x = (e.region_max[0] - o.x) * frx;
-    float t0y = (e.region_min[1] - o.y) * fry, t1y = (e.region_max[1] - o.y) * fry;
-    float t0z = (e.region_min[2] - o.z) * frz, t1z = (e.region_max[2] - o.z) * frz;
+    const float t0x = (e.region_min[0] - o.x) * frx, t1x = (e.region_max[0] - o.x) * frx;
+    const float t0y = (e.region_min[1] - o.y) * fry, t1y = (e.region_max[1] - o.y) * fry;
+    const float t0z = (e.region_min[2] - o.z) * frz, t1z = (e.region_max[2] - o.z) * frz;
     const float tmin = fmaxf(fmaxf(t0x, t0y), t0z);
     const float tmax = fminf(fminf(t1x, t1y), t1z);
-    if (!((tmin < tmax) && (tmax > 0.0f))) return false;
-
-    const int maxd = e.octree_depth;
-    uint32_t node = e.root_node;
-    int level = 0;
-    bool entering = true;
-    PtNode rec; rec.a = 0; rec.b = 0;
-    float tMx = 0.f, tMy = 0.f, tMz = 0.f;
-    int curr = 0;
-
-    for (;;) {
-        bool need_pop = false;
-        if (entering) {
-            st.node_visits++;
-            bool ok = !((t1x < 0.0f) || (t1y < 0.0f) || (t1y < 0.0f));
-            if (ok) rec = nodes[node];
-            if (ok && level == maxd) {
-                bool hit = false;
-                for (uint32_t i = 0; i < rec.b; i++)
-                    hit = intersect_record<LOG>(tris, rec.a + i, ro, rd, best, entity, st, lg) || hit;
-                if (hit) return true;
-                ok = false;
-            }
-            if (ok) {
-                tMx = 0.5f * (t0x + t1x); tMy = 0.5f * (t0y + t1y); tMz = 0.5f * (t0z + t1z);
-                curr = first_child(t0x, t0y, t0z, tMx, tMy, tMz);
-                entering = false;
-            } else {
-                need_pop = true;
-            }
-        } else if (curr >= 8) {
-            need_pop = true;
-        }
-        if (need_pop) {
-            if (level == 0) return false;
-            level--;
-            const float4 s = stack[level * stride];
-            const uint32_t w = __float_as_uint(s.w);
-            const int c = (int)(w & 7u);
-            node = w >> 3;
-            /* (t0,t1) still hold the child's interval: its t1 is the exit parameter set */
-            const float ex = t1x, ey = t1y, ez = t1z;
-            if (c & 4) { tMx = t0x; t0x = s.x; } else { tMx = t1x; t1x = s.x; }
-            if (c & 2) { tMy = t0y; t0y = s.y; } else { tMy = t1y; t1y = s.y; }
-            if (c & 1) { tMz = t0z; t0z = s.z; } else { tMz = t1z; t1z = s.z; }
-            rec = nodes[node];
-            curr = next_child(c, ex, ey, ez);
-            entering = false;
-            continue;
-        }
-        const int adj = curr ^ a;
-        if ((rec.b >> adj) & 1u) {
-            float4 s;
-            s.x = (curr & 4) ? t0x : t1x;
-            s.y = (curr & 2) ? t0y : t1y;
-            s.z = (curr & 1) ? t0z : t1z;
-            s.w = __uint_as_float((node << 3) | (uint32_t)curr);
-            stack[level * stride] = s;
-            if (curr & 4) t0x = tMx; else t1x = tMx;
-            if (curr & 2) t0y = tMy; else t1y = tMy;
-            if (curr & 1) t0z = tMz; else t1z = tMz;
-            node = rec.a + (uint32_t)__popc(rec.b & ((1u << adj) - 1u));
-            level++;
-            entering = true;
-        } else {
-            const float ex = (curr & 4) ? t1x : tMx;
-            const float ey = (curr & 2) ? t1y : tMy;
-            const float ez = (curr & 1) ? t1z : tMz;
-            curr = next_child(curr, ex, ey, ez);
-        }
-    }
+    if (!((tmin < tmax) && (tmax > 0.0f))) return;
+    if (STATS) st.node_visits++;          /* the root is entered */
+    if ((t1x < 0.0f) || (t1y < 0.0f) || (t1y < 0.0f)) return;   /* dgf:142 (tests y twice, never z) */
+    const PtNode rec = sc.nodes[e.root_node];
+    L.t0x = t0x; L.t0y = t0y; L.t0z = t0z; L.t1x = t1x; L.t1y = t1y; L.t1z = t1z;
+    L.nb = rec.a; L.nm = rec.b; L.nbase = e.root_node;
+    L.a = a; L.level = 0; L.path = 0; L.maxd = e.octree_depth;
+    L.curr = first_child(t0x, t0y, t0z, 0.5f * (t0x + t1x), 0.5f * (t0y + t1y), 0.5f * (t0z + t1z));
+    L.mode = M_NODE;
 }
 
-/* dgf:257-275; a sphere hit clears the triangle (the reference leaves a stale pointer) */
-__device__ __forceinline__ bool sphere_hit(const PtEntity &e, int32_t entity, V3 o, V3 d, Best &best) {
-    const V3 dd = o - mk(e.center[0], e.center[1], e.center[2]);
-    const float p1 = -dot3(d, dd);
-    const float p2sqr = ((p1 * p1) - dot3(dd, dd)) + (e.radius * e.radius);
-    if (p2sqr < 0) return false;
-    const float p2 = 1.0f / rsqrt_ieee(p2sqr);
-    const float t = p1 - p2 > 0 ? p1 - p2 : p1 + p2;
-    if (t > 0 && t < best.t) {
-        best.t = t; best.bu = 0.0f; best.bv = 0.0f;
-        best.entity = entity; best.tri = -1; best.rec = 0;
-        return true;
+/*
+ * NODE block: one step of proc_subtree's child loop (dgf:159-188) at the current inner node.
+ *   curr == 8            -> the node is exhausted: return to the parent (pop) or finish the walk;
+ *   child curr^a absent  -> advance curr;
+ *   child present        -> it is "entered" (counted); rejected by the dgf:142 test -> advance;
+ *                           at leaf depth -> becomes a triangle run, curr already advanced;
+ *                           otherwise -> push the frame and descend.
+ * Frames: descending, each axis of the child interval inherits one bound from the parent
+ * ([t0,tM] or [tM,t1]); the stack word keeps the three bounds the child does NOT inherit and the
+ * parent's {first child, mask}; the slot taken goes into `path`.  Returning, the parent's t0/t1
+ * are rebuilt from the child's interval and the saved bounds by copies only, and tM is recomputed
+ * by the same expression, so every value is the one the recursion would hold.
+ */
+template <bool STATS>
+__device__ __forceinline__ void node_block(const PtSceneDev &sc, Lane &L, Stats &st, float4 *stack, int stride) {
+    if (L.curr >= 8) {
+        if (L.level == 0) { L.mode = M_ENTITY; return; }     /* walk finished without an accepted leaf */
+        L.level--;
+        const float4 s = stack[L.level * stride];
+        const int c = (int)(L.path & 7u);
+        L.path >>= 3;
+        const uint32_t w = __float_as_uint(s.w);
+        /* (t0,t1) still hold the child's interval: its t1 is the exit parameter set of slot c */
+        const float ex = L.t1x, ey = L.t1y, ez = L.t1z;
+        /* value selects, not conditional stores: a store through a selected field address would
+         * force the whole lane state into scratch memory */
+        const float p0x = (c & 4) ? s.x : L.t0x, p1x = (c & 4) ? L.t1x : s.x;
+        const float p0y = (c & 2) ? s.y : L.t0y, p1y = (c & 2) ? L.t1y : s.y;
+        const float p0z = (c & 1) ? s.z : L.t0z, p1z = (c & 1) ? L.t1z : s.z;
+        L.t0x = p0x; L.t1x = p1x; L.t0y = p0y; L.t1y = p1y; L.t0z = p0z; L.t1z = p1z;
+        L.nb = L.nbase + (w >> 8);
+        L.nm = w & 0xFFu;
+        L.curr = next_child(c, ex, ey, ez);
+        return;
     }
-    return false;
+    const float tMx = 0.5f * (L.t0x + L.t1x), tMy = 0.5f * (L.t0y + L.t1y), tMz = 0.5f * (L.t0z + L.t1z);
+    const int curr = L.curr;
+    /* interval of child `curr` */
+    const float c0x = (curr & 4) ? tMx : L.t0x, c1x = (curr & 4) ? L.t1x : tMx;
+    const float c0y = (curr & 2) ? tMy : L.t0y, c1y = (curr & 2) ? L.t1y : tMy;
+    const float c0z = (curr & 1) ? tMz : L.t0z, c1z = (curr & 1) ? L.t1z : tMz;
+    const int nxt = next_child(curr, c1x, c1y, c1z);
+    const int adj = curr ^ L.a;
+    if (!((L.nm >> adj) & 1u)) { L.curr = nxt; return; }
+    if (STATS) st.node_visits++;
+    if ((c1x < 0.0f) || (c1y < 0.0f) || (c1y < 0.0f)) { L.curr = nxt; return; }   /* dgf:142 */
+    const uint32_t child = L.nb + (uint32_t)__popc(L.nm & ((1u << adj) - 1u));
+    const PtNode rec = sc.nodes[child];
+    if (L.level + 1 == L.maxd) {          /* leaf: dgf:146-157 */
+        L.curr = nxt;
+        if (rec.b != 0u) {
+            L.tri_cur = rec.a; L.tri_end = rec.a + rec.b;
+            L.run_flags = 2;
+            L.mode = M_LEAF;
+        }
+        return;
+    }
+    float4 s;
+    s.x = (curr & 4) ? L.t0x : L.t1x;
+    s.y = (curr & 2) ? L.t0y : L.t1y;
+    s.z = (curr & 1) ? L.t0z : L.t1z;
+    s.w = __uint_as_float(((L.nb - L.nbase) << 8) | L.nm);
+    stack[L.level * stride] = s;
+    L.path = (L.path << 3) | (uint32_t)curr;
+    L.level++;
+    L.t0x = c0x; L.t0y = c0y; L.t0z = c0z; L.t1x = c1x; L.t1y = c1y; L.t1z = c1z;
+    L.nb = rec.a; L.nm = rec.b;
+    L.curr = first_child(c0x, c0y, c0z, 0.5f * (c0x + c1x), 0.5f * (c0y + c1y), 0.5f * (c0z + c1z));
 }
 
-/* closest-hit part of trace() (dgf:201-206, 241-299): loops ALL entities with a shared best hit */
-template <bool LOG>
-__device__ __forceinline__ bool closest_hit(const PtSceneDev &sc, V3 o, V3 d, Best &best, Stats &st, TriLog &lg,
-                                            float4 *stack, int stride) {
-    st.segments++;
-    best.t = FLT_MAX; best.bu = 0.f; best.bv = 0.f; best.entity = -1; best.tri = -1; best.rec = 0;
-    const V3 fr = mk(clamp_frac(d.x), clamp_frac(d.y), clamp_frac(d.z));
-    bool is_hit = false;
-    for (int i = 0; i < sc.n_entities; i++) {
-        const PtEntity &e = sc.entities[i];
-        bool h = false;
-        if (e.shape == PT_SHAPE_SPHERE) {
-            h = sphere_hit(e, i, o, d, best);
-        } else {
-            st.aabb_tests++;
-            if (slab_test(e.aabb_min, e.aabb_max, o, fr, best.t)) {
-                if (e.octree_depth == 0) {
-                    for (uint32_t k = 0; k < e.n_tris; k++)
-                        h = intersect_record<LOG>(sc.tris, e.tri_first + k, o, d, best, i, st, lg) || h;
-                } else {
-                    h = octree_traverse<LOG>(sc.nodes, sc.tris, e, i, o, d, best, st, lg, stack, stride);
+/*
+ * LEAF block: one Moller-Trumbore test (dgf:319-365) on the pre-gathered record tri_cur; e1,e2
+ * were formed on the host by the same fp32 subtractions the reference performs per test.
+ *
+ * The reference divides by det before any comparison.  Here the three ratios are first formed
+ * with the hardware reciprocal (relative error < 3e-7): if one of them fails its test by more
+ * than a 1e-5 margin, the exactly rounded value fails it too and the test is rejected without the
+ * IEEE division; otherwise the exact sequence runs.  Accepted hits and every borderline case go
+ * through the exact path, so the outcome is bit-identical.
+ *
+ * When the run ends: an octree leaf that accepted a test ends the whole walk of this entity
+ * (dgf:188 unwinds every level once `hit` is set); otherwise the walk resumes; a brute-force run
+ * moves on to the next entity.
+ */
+template <bool STATS, bool LOG>
+__device__ __forceinline__ void leaf_block(const PtSceneDev &sc, Lane &L, Stats &st, TriLog &lg) {
+    const uint32_t idx = L.tri_cur;
+    const float4 *q = reinterpret_cast<const float4 *>(sc.tris + idx);
+    const float4 r0 = q[0], r1 = q[1], r2 = q[2];
+    L.tri_cur = idx + 1;
+    if (STATS) st.tri_tests++;
+    const int32_t id = __float_as_int(r2.y);
+    if (LOG) {
+        int n = lg.p[0]++;
+        if (n + 1 < lg.cap) lg.p[n + 1] = id;
+    }
+    const V3 v0 = mk(r0.x, r0.y, r0.z), e1 = mk(r0.w, r1.x, r1.y), e2 = mk(r1.z, r1.w, r2.x);
+    const V3 pvec = cross3(L.d, e2);
+    const float det = dot3(e1, pvec);
+    if (!(fabsf(det) < 0.000000001f)) {
+        const V3 tvec = L.o - v0;
+        const V3 qvec = cross3(tvec, e1);
+        const float un = dot3(tvec, pvec), vn = dot3(L.d, qvec), tn = dot3(e2, qvec);
+        const float ri = __builtin_amdgcn_rcpf(det);
+        const float ua = un * ri, va = vn * ri, ta = tn * ri;
+        const bool clearly_out = (ua < -0.00011f) || (ua > 1.00011f) || (va < -0.00011f) || (ua + va > 1.00012f) ||
+                                 (ta < -1e-30f) || (ta > L.best.t * 1.00001f);
+        if (!clearly_out) {
+            const float inv_det = 1.0f / det;
+            const float u = un * inv_det;
+            if (!(u < -0.0001f || u > 1.0001f)) {
+                const float v = vn * inv_det;
+                if (!(v < -0.0001f || u + v > 1.0001f)) {
+                    const float t = tn * inv_det;
+                    if (t > 0 && t < L.best.t) {
+                        L.best.t = t; L.best.bu = u; L.best.bv = v;
+                        L.best.entity = L.ent - 1; L.best.tri = id; L.best.rec = idx;
+                        L.run_flags |= 1;
+                    }
                 }
             }
         }
-        is_hit = h || is_hit;
     }
-    return is_hit;
+    if (L.tri_cur == L.tri_end) {
+        if ((L.run_flags & 2) && !(L.run_flags & 1)) L.mode = M_NODE;
+        else L.mode = M_ENTITY;
+    }
+}
+
+/*
+ * Runs the geometry blocks until no lane of the wave is in M_ENTITY / M_NODE / M_LEAF any more, or
+ * until at least `done_quota` lanes wait in M_DONE (so the caller can shade / refill them together).
+ * The block with the most waiting lanes runs next, for a few trips while it stays well filled.
+ */
+template <bool STATS, bool LOG>
+__device__ __forceinline__ void trace_wave(const PtSceneDev &sc, Lane &L, Stats &st, TriLog &lg, float4 *stack, int stride,
+                                           int done_quota) {
+    for (;;) {
+        const int n_ent = __popcll(__ballot(L.mode == M_ENTITY));
+        const int n_node = __popcll(__ballot(L.mode == M_NODE));
+        const int n_leaf = __popcll(__ballot(L.mode == M_LEAF));
+        if (n_ent + n_node + n_leaf == 0) return;
+        if (__popcll(__ballot(L.mode == M_DONE)) >= done_quota) return;
+        if (n_ent >= n_node && n_ent >= n_leaf) {
+            if (L.mode == M_ENTITY) entity_block<STATS>(sc, L, st);
+        } else if (n_node >= n_leaf) {
+            int trips = 0;
+            do {
+                if (L.mode == M_NODE) node_block<STATS>(sc, L, st, stack, stride);
+            } while (++trips < 8 && 2 * __popcll(__ballot(L.mode == M_NODE)) >= n_node);
+        } else {
+            int trips = 0;
+            do {
+                if (L.mode == M_LEAF) leaf_block<STATS, LOG>(sc, L, st, lg);
+            } while (++trips < 8 && 2 * __popcll(__ballot(L.mode == M_LEAF)) >= n_leaf);
+        }
+    }
 }
 
 struct Surface {     /* what shading needs from a hit */

@@ -58,9 +58,10 @@ __device__ __forceinline__ float tex_gray(const uint8_t *data, int w, int h, flo
 }
 
 /* src/scene.cuh:36-82 */
+template <bool STATS>
 __device__ __forceinline__ V3 sample_hdri(const PtSceneDev &sc, V3 v, Stats &st) {
     if (!sc.has_hdri) return mk(0.f, 0.f, 0.f);
-    st.env_lookups++;
+    if (STATS) st.env_lookups++;
     const int W = sc.hdri_w, H = sc.hdri_h;
     const float rn = rsqrt_ieee(v.x * v.x + 0.0f + v.z * v.z);
     const float vpx = v.x * rn, vpz = v.z * rn;
@@ -148,21 +149,22 @@ __device__ __forceinline__ void camera_ray(const pt_camera &cam, int u, int v, c
 
 /* One bounce of color() (src/renderer.cu:106-138) after a hit: samples the material, plays the
  * specular/diffuse roulette and replaces the ray.  xi = Philox block 1+bounce. */
+template <bool STATS>
 __device__ __forceinline__ void shade_hit(const PtSceneDev &sc, const Best &best, const Surface &sf, const float xi[4],
                                           V3 &o, V3 &d, V3 &atten, V3 &result, Stats &st) {
     const PtMaterial &m = sc.materials[sc.entities[best.entity].material];
     V3 ts_normal = mk(0.f, 0.f, 1.f);
     if (m.map[2]) {
-        st.tex_fetches++;
+        if (STATS) st.tex_fetches++;
         const V3 c = tex_rgb(m.map[2], m.map_w[2], m.map_h[2], sf.u, sf.v);
         ts_normal = fast_normalized(mk(2.0f * c.x - 1.0f, 2.0f * c.y - 1.0f, 2.0f * c.z - 1.0f));
     }
     V3 albedo = mk(m.albedo[0], m.albedo[1], m.albedo[2]);
-    if (m.map[0]) { st.tex_fetches++; albedo = tex_rgb(m.map[0], m.map_w[0], m.map_h[0], sf.u, sf.v); }
+    if (m.map[0]) { if (STATS) st.tex_fetches++; albedo = tex_rgb(m.map[0], m.map_w[0], m.map_h[0], sf.u, sf.v); }
     float smoothness = m.smoothness;
-    if (m.map[3]) { st.tex_fetches++; smoothness = tex_gray(m.map[3], m.map_w[3], m.map_h[3], sf.u, sf.v); }
+    if (m.map[3]) { if (STATS) st.tex_fetches++; smoothness = tex_gray(m.map[3], m.map_w[3], m.map_h[3], sf.u, sf.v); }
     V3 specular = mk(m.specular[0], m.specular[1], m.specular[2]);
-    if (m.map[1]) { st.tex_fetches++; specular = tex_rgb(m.map[1], m.map_w[1], m.map_h[1], sf.u, sf.v); }
+    if (m.map[1]) { if (STATS) st.tex_fetches++; specular = tex_rgb(m.map[1], m.map_w[1], m.map_h[1], sf.u, sf.v); }
     const float emission = m.emission;
     const V3 normal = to_world(ts_normal, tangent_space(sf.normal));
 
@@ -198,6 +200,9 @@ __device__ __forceinline__ void flush_stat(unsigned long long *dst, uint32_t v) 
     if ((threadIdx.x & 63) == 0) atomicAdd(dst, x);
 }
 
+/* lanes that wait in M_DONE before the wave leaves the geometry blocks to shade / refill them */
+static constexpr int kDoneQuota = 16;
+
 /* ------------------------------------------------------------------ closest-hit query kernel */
 template <bool LOG>
 __global__ void __launch_bounds__(kBlock) trace_kernel(PtSceneDev sc, const float *__restrict__ rays, int64_t n,
@@ -207,29 +212,44 @@ __global__ void __launch_bounds__(kBlock) trace_kernel(PtSceneDev sc, const floa
     float4 *stack = lds_stack + threadIdx.x;
     Stats st;
     stats_zero(st);
-    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
-        const V3 o = mk(rays[6 * i], rays[6 * i + 1], rays[6 * i + 2]);
-        const V3 d = mk(rays[6 * i + 3], rays[6 * i + 4], rays[6 * i + 5]);
-        TriLog lg;
-        lg.p = LOG ? log + i * log_stride : nullptr;
-        lg.cap = log_stride;
-        if (LOG) lg.p[0] = 0;
-        Best best;
-        const bool h = closest_hit<LOG>(sc, o, d, best, st, lg, stack, kBlock);
-        pt_hit out;
-        out.entity = -1; out.triangle = -1; out.t = best.t;
-        out.bu = out.bv = out.u = out.v = 0.f;
-        out.position[0] = out.position[1] = out.position[2] = 0.f;
-        out.normal[0] = out.normal[1] = out.normal[2] = 0.f;
-        if (h) {
-            Surface sf;
-            finish_hit(sc, o, d, best, sf);
-            out.entity = best.entity; out.triangle = best.tri;
-            out.bu = best.bu; out.bv = best.bv; out.u = sf.u; out.v = sf.v;
-            out.position[0] = sf.position.x; out.position[1] = sf.position.y; out.position[2] = sf.position.z;
-            out.normal[0] = sf.normal.x; out.normal[1] = sf.normal.y; out.normal[2] = sf.normal.z;
+    Lane L;
+    TriLog lg;
+    lg.p = nullptr; lg.cap = log_stride;
+    const int64_t step = (int64_t)gridDim.x * kBlock;
+    int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x - step;
+    L.mode = M_DONE;            /* "finished ray -1": the first trip only fetches */
+    bool first = true;
+    for (;;) {
+        if (L.mode == M_DONE) {
+            if (!first) {
+                pt_hit out;
+                out.entity = -1; out.triangle = -1; out.t = L.best.t;
+                out.bu = out.bv = out.u = out.v = 0.f;
+                out.position[0] = out.position[1] = out.position[2] = 0.f;
+                out.normal[0] = out.normal[1] = out.normal[2] = 0.f;
+                if (L.best.entity >= 0) {
+                    Surface sf;
+                    finish_hit(sc, L.o, L.d, L.best, sf);
+                    out.entity = L.best.entity; out.triangle = L.best.tri;
+                    out.bu = L.best.bu; out.bv = L.best.bv; out.u = sf.u; out.v = sf.v;
+                    out.position[0] = sf.position.x; out.position[1] = sf.position.y; out.position[2] = sf.position.z;
+                    out.normal[0] = sf.normal.x; out.normal[1] = sf.normal.y; out.normal[2] = sf.normal.z;
+                }
+                hits[i] = out;
+            }
+            i += step;
+            if (i < n) {
+                st.segments++;
+                lane_start_ray(L, mk(rays[6 * i], rays[6 * i + 1], rays[6 * i + 2]),
+                               mk(rays[6 * i + 3], rays[6 * i + 4], rays[6 * i + 5]));
+                if (LOG) { lg.p = log + i * log_stride; lg.p[0] = 0; }
+            } else {
+                L.mode = M_IDLE;
+            }
         }
-        hits[i] = out;
+        first = false;
+        if (__ballot(L.mode != M_IDLE) == 0ull) break;
+        trace_wave<true, LOG>(sc, L, st, lg, stack, kBlock, kDoneQuota);
     }
     if (stats) {
         flush_stat(&stats[0], st.segments);
@@ -262,6 +282,7 @@ __device__ __forceinline__ void slice_range(const SlicePlan &pl, int slice, int 
     s1 = zb + (int)((M * (j + 1)) / pl.slices_per_split);
 }
 
+template <bool STATS>
 __global__ void __launch_bounds__(kBlock) render_kernel(RenderParams P) {
     extern __shared__ float4 lds_stack[];
     float4 *stack = lds_stack + threadIdx.x;
@@ -275,24 +296,52 @@ __global__ void __launch_bounds__(kBlock) render_kernel(RenderParams P) {
     int pool_next = 64;
     bool exhausted = false;
 
-    /* lane state */
-    int pixel = -1, px = 0, py = 0, slice = 0, s_cur = 0, s_end = 0;
-    bool done = false, path_active = false;
+    /* lane state: the (pixel, slice) it owns, the path it is extending, the ray it is tracing */
+    int pixel = -1, pxy = 0, slice = 0, s_cur = 0, s_end = 0, bounce = 0;
+    bool done = false;          /* no more work for this lane */
     V3 accum = mk(0.f, 0.f, 0.f), result = mk(0.f, 0.f, 0.f), atten = mk(1.f, 1.f, 1.f);
-    V3 o = mk(0.f, 0.f, 0.f), d = mk(0.f, 0.f, 1.f);
-    int bounce = 0;
+    Lane L;
+    L.mode = M_IDLE;
     Stats st;
     stats_zero(st);
     TriLog lg;
     lg.p = nullptr; lg.cap = 0;
 
     for (;;) {
-        if (!path_active && pixel >= 0 && s_cur >= s_end) {
+        /* ---- shade the lanes whose ray is finished (color()'s loop body, src/renderer.cu:99-139) */
+        if (L.mode == M_DONE) {
+            bool ended;
+            if (L.best.entity < 0) {
+                const V3 env = sample_hdri<STATS>(P.sc, L.d, st);
+                result = result + atten * env;
+                ended = true;
+            } else {
+                Surface sf;
+                finish_hit(P.sc, L.o, L.d, L.best, sf);
+                float xi[4];
+                rng_block((uint32_t)pixel, (uint32_t)s_cur, 1u + (uint32_t)bounce, P.seed, xi);
+                V3 o = L.o, d = L.d;
+                shade_hit<STATS>(P.sc, L.best, sf, xi, o, d, atten, result, st);
+                bounce++;
+                ended = bounce >= 6;   /* src/renderer.cu:99 */
+                if (!ended) {
+                    if (STATS) st.segments++;
+                    lane_start_ray(L, o, d);
+                }
+            }
+            if (ended) {
+                accum = accum + result;
+                s_cur++;
+                L.mode = M_IDLE;
+            }
+        }
+        /* ---- lanes without a path: finish their (pixel, slice), take a new one, start the next sample */
+        if (L.mode == M_IDLE && pixel >= 0 && s_cur >= s_end) {
             float *out = P.partials + 3 * ((size_t)slice * n_pixels + (size_t)pixel);
             out[0] = accum.x; out[1] = accum.y; out[2] = accum.z;
             pixel = -1;
         }
-        const bool wants = !path_active && !done && pixel < 0;
+        const bool wants = L.mode == M_IDLE && !done && pixel < 0;
         const unsigned long long need = __ballot(wants);
         if (need != 0ull) {
             const int n_need = __popcll(need);
@@ -327,55 +376,34 @@ __global__ void __launch_bounds__(kBlock) render_kernel(RenderParams P) {
                     const uint32_t tile = my_item / (uint32_t)n_slices;
                     slice = (int)(my_item - tile * (uint32_t)n_slices);
                     const int tx = (int)(tile % (uint32_t)P.tiles_x), ty = (int)(tile / (uint32_t)P.tiles_x);
-                    px = tx * 8 + (my_slot & 7);
-                    py = ty * 8 + (my_slot >> 3);
+                    const int px = tx * 8 + (my_slot & 7), py = ty * 8 + (my_slot >> 3);
                     if (px < W && py < H) {
                         pixel = py * W + px;
+                        pxy = (py << 16) | px;
                         slice_range(P.plan, slice, s_cur, s_end);
                         accum = mk(0.f, 0.f, 0.f);
                     }
                 }
             }
         }
-        if (!path_active && pixel >= 0 && s_cur < s_end) {
+        if (L.mode == M_IDLE && pixel >= 0 && s_cur < s_end) {
             float xi[4];
             rng_block((uint32_t)pixel, (uint32_t)s_cur, 0u, P.seed, xi);
-            camera_ray(P.cam, px, py, xi, o, d);
+            V3 o, d;
+            camera_ray(P.cam, pxy & 0xFFFF, pxy >> 16, xi, o, d);
             atten = mk(1.f, 1.f, 1.f);
             result = mk(0.f, 0.f, 0.f);
             bounce = 0;
-            path_active = true;
-            st.paths++;
+            if (STATS) { st.paths++; st.segments++; }
+            lane_start_ray(L, o, d);
         }
-        if (__ballot(path_active) == 0ull) {
-            if (__ballot(!done) == 0ull) break;
-            continue;
+        if (__ballot(L.mode != M_IDLE) == 0ull) {
+            if (__ballot(!done) == 0ull) break;      /* every lane is out of work: the grid drains */
+            continue;                                /* e.g. lanes that drew an out-of-image slot ask again */
         }
-        if (path_active) {
-            Best best;
-            const bool h = closest_hit<false>(P.sc, o, d, best, st, lg, stack, kBlock);
-            bool ended;
-            if (!h) {
-                const V3 env = sample_hdri(P.sc, d, st);
-                result = result + atten * env;
-                ended = true;
-            } else {
-                Surface sf;
-                finish_hit(P.sc, o, d, best, sf);
-                float xi[4];
-                rng_block((uint32_t)pixel, (uint32_t)s_cur, 1u + (uint32_t)bounce, P.seed, xi);
-                shade_hit(P.sc, best, sf, xi, o, d, atten, result, st);
-                bounce++;
-                ended = bounce >= 6;   /* src/renderer.cu:99 */
-            }
-            if (ended) {
-                accum = accum + result;
-                s_cur++;
-                path_active = false;
-            }
-        }
+        trace_wave<STATS, false>(P.sc, L, st, lg, stack, kBlock, kDoneQuota);
     }
-    if (P.stats) {
+    if (STATS && P.stats) {
         flush_stat(&P.stats[0], st.segments);
         flush_stat(&P.stats[1], st.aabb_tests);
         flush_stat(&P.stats[2], st.node_visits);
@@ -458,7 +486,10 @@ int launch_render(const RenderParams &p, int n_cu, hipStream_t stream) {
     const int64_t max_useful = ((int64_t)p.n_items * 64 + kBlock - 1) / kBlock;
     if (blocks > max_useful) blocks = max_useful;
     if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL(render_kernel, dim3((unsigned)blocks), dim3(kBlock), lds, stream, p);
+    if (p.stats)
+        hipLaunchKernelGGL(render_kernel<true>, dim3((unsigned)blocks), dim3(kBlock), lds, stream, p);
+    else
+        hipLaunchKernelGGL(render_kernel<false>, dim3((unsigned)blocks), dim3(kBlock), lds, stream, p);
     PT_HIP(hipGetLastError());
     return 0;
 }
