@@ -109,6 +109,8 @@ def main():
         step()
     # one untimed pass with the in-kernel work counters (identical work: same seed, same samples)
     counters = step(want_counters=True)
+    torch.cuda.synchronize()
+    schedule = scene.schedule_counters()
     scene.set_profiling(True)
     fence()
     kernel_ms = []
@@ -183,7 +185,7 @@ def main():
                        "spp": spp, "samples_per_rank": s_end - s_begin, "parallelism": f"sample-shard x{world}"},
             "time_to_spp_s": round(ms_per_step / 1000.0, 4),
             "msegments_per_s": round(total_counters["segments"] / (ms_per_step / 1000.0) / 1e6, 2),
-            "counters": total_counters,
+            "counters": total_counters, "schedule": schedule,
             "roofline": roofline, "cpu_baseline": cpu_baseline,
             "post_chain_ms": None if post_ms is None else round(post_ms, 2),
             "scene_gen_s": round(t_gen, 2), "scene_build_upload_s": round(t_upload, 2),

@@ -395,7 +395,7 @@ int pt_scene_commit(pt_scene *scene) {
     scene->dev = d;
 
     PT_HIP(hipMalloc((void **)&scene->d_counter, sizeof(uint32_t)));
-    PT_HIP(hipMalloc((void **)&scene->d_stats, 7 * sizeof(unsigned long long)));
+    PT_HIP(hipMalloc((void **)&scene->d_stats, 16 * sizeof(unsigned long long)));
     scene->committed = true;
     return 0;
 }
@@ -474,7 +474,7 @@ int pt_trace_rays(pt_scene *scene, const float *rays, int64_t n, pt_hit *hits, i
             /* entries past a ray's test count read as 0 */
             if (hipMemsetAsync(tmp_log, 0, (size_t)n * log_stride * 4, stream) != hipSuccess) { rc = 1; set_error("pt_trace_rays: memset failed"); break; }
         }
-        if (counters && hipMemsetAsync(scene->d_stats, 0, 7 * sizeof(unsigned long long), stream) != hipSuccess) { rc = 1; set_error("pt_trace_rays: memset failed"); break; }
+        if (counters && hipMemsetAsync(scene->d_stats, 0, 16 * sizeof(unsigned long long), stream) != hipSuccess) { rc = 1; set_error("pt_trace_rays: memset failed"); break; }
         rc = launch_trace(scene->dev, d_rays, n, d_hits, d_log, log_stride, counters ? scene->d_stats : nullptr, stream);
         if (rc) break;
         if (!hits_dev && hipMemcpyAsync(hits, d_hits, (size_t)n * sizeof(pt_hit), hipMemcpyDeviceToHost, stream) != hipSuccess) { rc = 1; set_error("pt_trace_rays: hit download failed"); break; }
@@ -554,7 +554,7 @@ int pt_render_accumulate(pt_scene *scene, const pt_camera *camera, uint32_t seed
     p.counter = scene->d_counter;
     p.stats = counters ? scene->d_stats : nullptr;
     PT_HIP(hipMemsetAsync(scene->d_counter, 0, sizeof(uint32_t), stream));
-    if (counters) PT_HIP(hipMemsetAsync(scene->d_stats, 0, 7 * sizeof(unsigned long long), stream));
+    if (counters) PT_HIP(hipMemsetAsync(scene->d_stats, 0, 16 * sizeof(unsigned long long), stream));
     if (scene->profiling) {
         if (!scene->ev_start) {
             PT_HIP(hipEventCreate(&scene->ev_start));
@@ -574,6 +574,16 @@ int pt_render_accumulate(pt_scene *scene, const pt_camera *camera, uint32_t seed
         PT_HIP(hipStreamSynchronize(stream));
         counters_from(h, counters);
     }
+    return 0;
+}
+
+int pt_scene_schedule_counters(pt_scene *scene, uint64_t out[8]) {
+    if (!scene || !out) PT_FAIL("pt_scene_schedule_counters: null argument");
+    if (!scene->committed) PT_FAIL("pt_scene_schedule_counters: scene not committed");
+    DeviceGuard g(scene->device);
+    unsigned long long h[16];
+    PT_HIP(hipMemcpy(h, scene->d_stats, sizeof h, hipMemcpyDeviceToHost));
+    for (int i = 0; i < 8; i++) out[i] = h[7 + i];
     return 0;
 }
 

@@ -56,9 +56,13 @@ __device__ __forceinline__ float clamp_frac(float d) { return fmaxf(fminf(1.0f /
 
 struct Stats {
     uint32_t segments, aabb_tests, node_visits, tri_tests, env_lookups, tex_fetches, paths;
+    /* scheduling diagnostics (per lane: trips of each block this lane took part in; lane 0 also
+     * counts the trips its wave ran, so lanes / (64 * trips) is the block's lane occupancy) */
+    uint32_t ent_lanes, node_lanes, leaf_lanes, front_lanes, ent_trips, node_trips, leaf_trips, front_trips;
 };
 __device__ __forceinline__ void stats_zero(Stats &s) {
     s.segments = s.aabb_tests = s.node_visits = s.tri_tests = s.env_lookups = s.tex_fetches = s.paths = 0;
+    s.ent_lanes = s.node_lanes = s.leaf_lanes = s.front_lanes = s.ent_trips = s.node_trips = s.leaf_trips = s.front_trips = 0;
 }
 
 struct Best {
@@ -72,6 +76,10 @@ struct TriLog {        /* optional per-ray record of the triangle-test sequence 
     int32_t *p;
     int32_t cap;
 };
+
+#ifndef PT_TRIPS
+#define PT_TRIPS 8
+#endif
 
 enum : int { M_ENTITY = 0, M_NODE = 1, M_LEAF = 2, M_DONE = 3, M_IDLE = 4 };
 
@@ -349,17 +357,22 @@ __device__ __forceinline__ void trace_wave(const PtSceneDev &sc, Lane &L, Stats 
         if (n_ent + n_node + n_leaf == 0) return;
         if (__popcll(__ballot(L.mode == M_DONE)) >= done_quota) return;
         if (n_ent >= n_node && n_ent >= n_leaf) {
-            if (L.mode == M_ENTITY) entity_block<STATS>(sc, L, st);
+            if (STATS) st.ent_trips++;
+            if (L.mode == M_ENTITY) { if (STATS) st.ent_lanes++; entity_block<STATS>(sc, L, st); }
         } else if (n_node >= n_leaf) {
             int trips = 0;
+#pragma nounroll
             do {
-                if (L.mode == M_NODE) node_block<STATS>(sc, L, st, stack, stride);
-            } while (++trips < 8 && 2 * __popcll(__ballot(L.mode == M_NODE)) >= n_node);
+                if (STATS) st.node_trips++;
+                if (L.mode == M_NODE) { if (STATS) st.node_lanes++; node_block<STATS>(sc, L, st, stack, stride); }
+            } while (++trips < PT_TRIPS && 2 * __popcll(__ballot(L.mode == M_NODE)) >= n_node);
         } else {
             int trips = 0;
+#pragma nounroll
             do {
-                if (L.mode == M_LEAF) leaf_block<STATS, LOG>(sc, L, st, lg);
-            } while (++trips < 8 && 2 * __popcll(__ballot(L.mode == M_LEAF)) >= n_leaf);
+                if (STATS) st.leaf_trips++;
+                if (L.mode == M_LEAF) { if (STATS) st.leaf_lanes++; leaf_block<STATS, LOG>(sc, L, st, lg); }
+            } while (++trips < PT_TRIPS && 2 * __popcll(__ballot(L.mode == M_LEAF)) >= n_leaf);
         }
     }
 }

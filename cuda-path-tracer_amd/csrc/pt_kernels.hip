@@ -201,7 +201,14 @@ __device__ __forceinline__ void flush_stat(unsigned long long *dst, uint32_t v) 
 }
 
 /* lanes that wait in M_DONE before the wave leaves the geometry blocks to shade / refill them */
-static constexpr int kDoneQuota = 16;
+#ifndef PT_DONE_QUOTA
+#define PT_DONE_QUOTA 16
+#endif
+static constexpr int kDoneQuota = PT_DONE_QUOTA;
+/* minimum waves per SIMD the register allocator must leave room for */
+#ifndef PT_WAVES_PER_EU
+#define PT_WAVES_PER_EU 3
+#endif
 
 /* ------------------------------------------------------------------ closest-hit query kernel */
 template <bool LOG>
@@ -283,7 +290,7 @@ __device__ __forceinline__ void slice_range(const SlicePlan &pl, int slice, int 
 }
 
 template <bool STATS>
-__global__ void __launch_bounds__(kBlock) render_kernel(RenderParams P) {
+__global__ void __launch_bounds__(kBlock, PT_WAVES_PER_EU) render_kernel(RenderParams P) {
     extern __shared__ float4 lds_stack[];
     float4 *stack = lds_stack + threadIdx.x;
     const int lane = threadIdx.x & 63;
@@ -309,7 +316,9 @@ __global__ void __launch_bounds__(kBlock) render_kernel(RenderParams P) {
 
     for (;;) {
         /* ---- shade the lanes whose ray is finished (color()'s loop body, src/renderer.cu:99-139) */
+        if (STATS) st.front_trips++;
         if (L.mode == M_DONE) {
+            if (STATS) st.front_lanes++;
             bool ended;
             if (L.best.entity < 0) {
                 const V3 env = sample_hdri<STATS>(P.sc, L.d, st);
@@ -411,6 +420,15 @@ __global__ void __launch_bounds__(kBlock) render_kernel(RenderParams P) {
         flush_stat(&P.stats[4], st.env_lookups);
         flush_stat(&P.stats[5], st.tex_fetches);
         flush_stat(&P.stats[6], st.paths);
+        flush_stat(&P.stats[7], st.ent_lanes);
+        flush_stat(&P.stats[8], st.node_lanes);
+        flush_stat(&P.stats[9], st.leaf_lanes);
+        flush_stat(&P.stats[10], st.front_lanes);
+        /* trips are wave-uniform: count them once per wave */
+        flush_stat(&P.stats[11], lane == 0 ? st.ent_trips : 0u);
+        flush_stat(&P.stats[12], lane == 0 ? st.node_trips : 0u);
+        flush_stat(&P.stats[13], lane == 0 ? st.leaf_trips : 0u);
+        flush_stat(&P.stats[14], lane == 0 ? st.front_trips : 0u);
     }
 }
 
@@ -479,7 +497,7 @@ int launch_render(const RenderParams &p, int n_cu, hipStream_t stream) {
     const size_t lds = stack_bytes(p.sc.max_depth);
     /* persistent grid: as many workgroups as stay resident (registers allow 4 waves per SIMD =
      * 4 workgroups of 256 threads per CU; LDS allows 160 KiB / lds) */
-    int per_cu = 4;
+    int per_cu = PT_WAVES_PER_EU;
     const int by_lds = (int)((160 * 1024) / (lds ? lds : 1));
     if (by_lds < per_cu) per_cu = by_lds > 0 ? by_lds : 1;
     int64_t blocks = (int64_t)n_cu * per_cu;

@@ -11,7 +11,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 PKG_ROOT = os.path.dirname(os.path.dirname(_HERE))
-LIB_PATH = os.path.join(PKG_ROOT, "lib", "libptamd.so")
+LIB_PATH = os.environ.get("PTAMD_LIB") or os.path.join(PKG_ROOT, "lib", "libptamd.so")
 PT_MAX_OCTREE_DEPTH = 12
 
 
@@ -57,7 +57,7 @@ ABI_SYMBOLS = [
     "pt_last_error", "pt_device_count", "pt_device_name", "pt_scene_create", "pt_scene_destroy", "pt_scene_add_material",
     "pt_scene_add_mesh", "pt_scene_add_sphere", "pt_scene_set_hdri", "pt_scene_commit", "pt_scene_octree_info",
     "pt_scene_octree_dump", "pt_scene_device_bytes", "pt_trace_rays", "pt_camera_rays", "pt_render_accumulate",
-    "pt_scene_set_profiling", "pt_scene_last_render_kernel_ms", "pt_compound_buffers", "pt_apply_filter", "pt_make_gaussian", "pt_make_mean", "pt_normalize_image", "pt_apply_threshold",
+    "pt_scene_set_profiling", "pt_scene_schedule_counters", "pt_scene_last_render_kernel_ms", "pt_compound_buffers", "pt_apply_filter", "pt_make_gaussian", "pt_make_mean", "pt_normalize_image", "pt_apply_threshold",
     "pt_image_add", "pt_apply_aces", "pt_gamma_correct", "pt_post_chain", "pt_malloc", "pt_free", "pt_memset", "pt_upload",
     "pt_download", "pt_stream_synchronize",
 ]
@@ -90,6 +90,7 @@ def lib():
         L.pt_camera_rays.argtypes = [i32, C.POINTER(Camera), u32, i32, vp, vp]
         L.pt_render_accumulate.argtypes = [vp, C.POINTER(Camera), u32, i32, i32, i32, vp, vp, vp]
         L.pt_scene_set_profiling.argtypes = [vp, i32]
+        L.pt_scene_schedule_counters.argtypes = [vp, vp]
         L.pt_scene_last_render_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
         L.pt_compound_buffers.argtypes = [i32, vp, vp, i64, i32, vp]
         L.pt_apply_filter.argtypes = [i32, vp, vp, i32, i32, vp, i32, i32, vp]
@@ -273,6 +274,13 @@ class Scene:
                                           C.byref(cnt) if want_counters else None, stream))
         return cnt.as_dict() if want_counters else None
 
+
+    def schedule_counters(self):
+        out = (C.c_uint64 * 8)()
+        check(self.L.pt_scene_schedule_counters(self.h, out))
+        names = ["ent", "node", "leaf", "front"]
+        v = [int(x) for x in out]
+        return {n: dict(lanes=v[i], trips=v[4 + i], occupancy=(v[i] / (64.0 * v[4 + i]) if v[4 + i] else 0.0)) for i, n in enumerate(names)}
 
     def set_profiling(self, enable=True):
         check(self.L.pt_scene_set_profiling(self.h, int(bool(enable))))

@@ -150,6 +150,9 @@ int pt_render_accumulate(pt_scene *scene, const pt_camera *camera, uint32_t seed
  * brackets its path-tracing kernel with two HIP events on the launch stream;
  * pt_scene_last_render_kernel_ms waits for the last launch and returns its duration. */
 int pt_scene_set_profiling(pt_scene *scene, int enable);
+/* Scheduling diagnostics of the last pt_render_accumulate that asked for counters: lanes that took
+ * part in {entity, node, leaf, shading} block trips, then the number of wave-level trips of each. */
+int pt_scene_schedule_counters(pt_scene *scene, uint64_t out[8]);
 int pt_scene_last_render_kernel_ms(pt_scene *scene, float *ms);
 /* d_out[p] = sum_z d_split[z][p]  (compound_buffers, src/post_processing.cu:243-256); device ptrs */
 int pt_compound_buffers(int device, const float *d_split, float *d_out, int64_t n_pixels,
