@@ -69,7 +69,7 @@ struct pt_scene {
     uint64_t bytes_nodes = 0, bytes_tris = 0, bytes_shade = 0, bytes_tex = 0, bytes_hdri = 0;
 
     DevBuf partials;                    /* render workspace, grown on demand */
-    uint32_t *d_counter = nullptr;
+    uint32_t *d_tickets = nullptr;      /* kMaxQueues work-queue cursors */
     unsigned long long *d_stats = nullptr;
 
     bool profiling = false;             /* bracket the render kernel with HIP events */
@@ -78,6 +78,8 @@ struct pt_scene {
 };
 
 namespace {
+
+constexpr int kMaxQueues = 4096;     /* upper bound on the persistent grid (workgroups) */
 
 struct DeviceGuard {
     int prev = -1;
@@ -120,9 +122,9 @@ void free_device_side(pt_scene *s) {
     s->allocs.clear();
     if (s->partials.p) (void)hipFree(s->partials.p);
     s->partials = DevBuf();
-    if (s->d_counter) (void)hipFree(s->d_counter);
+    if (s->d_tickets) (void)hipFree(s->d_tickets);
     if (s->d_stats) (void)hipFree(s->d_stats);
-    s->d_counter = nullptr;
+    s->d_tickets = nullptr;
     s->d_stats = nullptr;
     if (s->ev_start) (void)hipEventDestroy(s->ev_start);
     if (s->ev_stop) (void)hipEventDestroy(s->ev_stop);
@@ -394,7 +396,7 @@ int pt_scene_commit(pt_scene *scene) {
     d.max_depth = max_depth;
     scene->dev = d;
 
-    PT_HIP(hipMalloc((void **)&scene->d_counter, sizeof(uint32_t)));
+    PT_HIP(hipMalloc((void **)&scene->d_tickets, kMaxQueues * sizeof(uint32_t)));
     PT_HIP(hipMalloc((void **)&scene->d_stats, 16 * sizeof(unsigned long long)));
     scene->committed = true;
     return 0;
@@ -536,8 +538,10 @@ int pt_render_accumulate(pt_scene *scene, const pt_camera *camera, uint32_t seed
     p.plan = make_slice_plan(sample_begin, sample_end, n_split);
     p.tiles_x = (camera->res_x + 7) / 8;
     p.tiles_y = (camera->res_y + 7) / 8;
+    p.mtiles_x = (p.tiles_x + 7) / 8;
+    p.mtiles_y = (p.tiles_y + 7) / 8;
     const int n_slices = p.plan.n_split * p.plan.slices_per_split;
-    const uint64_t n_items = (uint64_t)p.tiles_x * p.tiles_y * n_slices;
+    const uint64_t n_items = (uint64_t)p.mtiles_x * p.mtiles_y * 64 * n_slices;
     if (n_items >= 0xFFFF0000ull) PT_FAIL("pt_render_accumulate: too many work items");
     p.n_items = (uint32_t)n_items;
     const int64_t n_pixels = (int64_t)camera->res_x * camera->res_y;
@@ -551,9 +555,9 @@ int pt_render_accumulate(pt_scene *scene, const pt_camera *camera, uint32_t seed
         scene->partials.bytes = need;
     }
     p.partials = (float *)scene->partials.p;
-    p.counter = scene->d_counter;
+    p.tickets = scene->d_tickets;
     p.stats = counters ? scene->d_stats : nullptr;
-    PT_HIP(hipMemsetAsync(scene->d_counter, 0, sizeof(uint32_t), stream));
+    PT_HIP(hipMemsetAsync(scene->d_tickets, 0, kMaxQueues * sizeof(uint32_t), stream));
     if (counters) PT_HIP(hipMemsetAsync(scene->d_stats, 0, 16 * sizeof(unsigned long long), stream));
     if (scene->profiling) {
         if (!scene->ev_start) {
@@ -562,7 +566,7 @@ int pt_render_accumulate(pt_scene *scene, const pt_camera *camera, uint32_t seed
         }
         PT_HIP(hipEventRecord(scene->ev_start, stream));
     }
-    if (launch_render(p, scene->n_cu, stream)) return 1;
+    if (launch_render(p, scene->n_cu, kMaxQueues, stream)) return 1;
     if (scene->profiling) {
         PT_HIP(hipEventRecord(scene->ev_stop, stream));
         scene->ev_valid = true;

@@ -77,6 +77,16 @@ struct TriLog {        /* optional per-ray record of the triangle-test sequence 
     int32_t cap;
 };
 
+/* one-trip-ahead request of the next triangle record's cache line */
+#ifndef PT_USE_TOUCH
+#define PT_USE_TOUCH 0
+#endif
+#if PT_USE_TOUCH
+#define PT_TOUCH(L, ptr) (L).touch = *reinterpret_cast<const uint32_t *>(ptr)
+#else
+#define PT_TOUCH(L, ptr) ((void)0)
+#endif
+
 #ifndef PT_TRIPS
 #define PT_TRIPS 8
 #endif
@@ -99,6 +109,7 @@ struct Lane {
     /* triangle run (octree leaf or brute-force mesh) */
     uint32_t tri_cur, tri_end;
     int32_t run_flags;       /* bit0: some test of this run was accepted, bit1: run is an octree leaf */
+    uint32_t touch;          /* first word of the NEXT record, requested one trip ahead (see leaf_block) */
 };
 
 /* dgf:116-126 with the per-child argument table of dgf:178-187 folded in: the exit parameters of
@@ -185,6 +196,7 @@ __device__ __forceinline__ void entity_block(const PtSceneDev &sc, Lane &L, Stat
         L.tri_cur = e.tri_first; L.tri_end = e.tri_first + e.n_tris;
         L.run_flags = 0;
         L.mode = M_LEAF;
+        PT_TOUCH(L, sc.tris + e.tri_first);
         return;
     }
     V3 o = L.o, d = L.d;
@@ -267,6 +279,7 @@ __device__ __forceinline__ void node_block(const PtSceneDev &sc, Lane &L, Stats 
             L.tri_cur = rec.a; L.tri_end = rec.a + rec.b;
             L.run_flags = 2;
             L.mode = M_LEAF;
+            PT_TOUCH(L, sc.tris + rec.a);
         }
         return;
     }
@@ -301,8 +314,14 @@ template <bool STATS, bool LOG>
 __device__ __forceinline__ void leaf_block(const PtSceneDev &sc, Lane &L, Stats &st, TriLog &lg) {
     const uint32_t idx = L.tri_cur;
     const float4 *q = reinterpret_cast<const float4 *>(sc.tris + idx);
+#if PT_USE_TOUCH
+    /* the word requested on the previous trip has to have landed before this record's three loads
+     * go out: they then hit a line that is resident instead of queueing behind its pending miss */
+    asm volatile("" ::"v"(L.touch));
+#endif
     const float4 r0 = q[0], r1 = q[1], r2 = q[2];
     L.tri_cur = idx + 1;
+    if (L.tri_cur != L.tri_end) PT_TOUCH(L, sc.tris + idx + 1);
     if (STATS) st.tri_tests++;
     const int32_t id = __float_as_int(r2.y);
     if (LOG) {

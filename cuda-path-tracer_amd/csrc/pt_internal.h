@@ -41,9 +41,11 @@ struct RenderParams {
     pt_camera cam;
     uint32_t seed;
     SlicePlan plan;
-    int tiles_x, tiles_y;
-    uint32_t n_items;
-    uint32_t *counter;           /* work-item ticket, zeroed before the launch */
+    int tiles_x, tiles_y;        /* 8x8-pixel tiles covering the image */
+    int mtiles_x, mtiles_y;      /* 8x8-tile macro tiles covering the tiles */
+    uint32_t n_items;            /* mtiles_x * mtiles_y * 64 tiles * slices */
+    uint32_t n_queues;           /* == gridDim.x: every workgroup owns one contiguous range of the items */
+    uint32_t *tickets;           /* n_queues cursors, zeroed before the launch */
     float *partials;             /* [n_split * slices_per_split][H*W][3] */
     unsigned long long *stats;   /* 7 counters, or null */
 };
@@ -52,7 +54,7 @@ struct RenderParams {
 int launch_trace(const PtSceneDev &sc, const float *d_rays, int64_t n, pt_hit *d_hits, int32_t *d_log,
                  int log_stride, unsigned long long *d_stats, hipStream_t stream);
 int launch_camera_rays(const pt_camera &cam, uint32_t seed, int sample, float *d_rays, hipStream_t stream);
-int launch_render(const RenderParams &p, int n_cu, hipStream_t stream);
+int launch_render(RenderParams p, int n_cu, int max_queues, hipStream_t stream);
 int launch_compound_partials(const float *d_partials, float *d_split, int64_t n_pixels, const SlicePlan &plan,
                              hipStream_t stream);
 int launch_compound_split(const float *d_split, float *d_out, int64_t n_pixels, int n_split, hipStream_t stream);

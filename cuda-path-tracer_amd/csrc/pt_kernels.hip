@@ -302,6 +302,17 @@ __global__ void __launch_bounds__(kBlock, PT_WAVES_PER_EU) render_kernel(RenderP
     uint32_t pool_item = 0;
     int pool_next = 64;
     bool exhausted = false;
+    /* Work queues.  The item space (macro-tile order, all slices of a tile adjacent) is cut into one
+     * contiguous range per workgroup, so the waves of a workgroup -- which share a CU and its L1 --
+     * trace neighbouring pixels; workgroups b, b+8, ... tend to share an XCD and its L2 (a speed
+     * matter only), so they get adjacent ranges.  A wave whose range is empty steals from the next. */
+    const uint32_t nq = P.n_queues;
+    uint32_t q;
+    {
+        const uint32_t b = blockIdx.x, per = nq / 8u, rem = nq % 8u, x = b % 8u;
+        q = (x < rem ? x * (per + 1u) : rem * (per + 1u) + (x - rem) * per) + b / 8u;      /* bijective on [0, nq) */
+    }
+    uint32_t probes = 0;
 
     /* lane state: the (pixel, slice) it owns, the path it is extending, the ray it is tracing */
     int pixel = -1, pxy = 0, slice = 0, s_cur = 0, s_end = 0, bounce = 0;
@@ -362,10 +373,21 @@ __global__ void __launch_bounds__(kBlock, PT_WAVES_PER_EU) render_kernel(RenderP
             while (assigned < n_need) {
                 if (pool_next >= 64) {
                     if (exhausted) break;
-                    uint32_t id = 0;
-                    if (lane == 0) id = atomicAdd(P.counter, 1u);
+                    uint32_t id = 0xFFFFFFFFu;
+                    if (lane == 0) {
+                        for (;;) {
+                            const uint32_t lo = (uint32_t)(((unsigned long long)P.n_items * q) / nq);
+                            const uint32_t hi = (uint32_t)(((unsigned long long)P.n_items * (q + 1u)) / nq);
+                            const uint32_t t = atomicAdd(&P.tickets[q], 1u);
+                            if (t < hi - lo) { id = lo + t; break; }
+                            q = (q + 1u == nq) ? 0u : q + 1u;        /* this range is finished for good: move on */
+                            if (++probes >= nq) break;               /* every range has been seen empty */
+                        }
+                    }
                     id = (uint32_t)__builtin_amdgcn_readfirstlane((int)id);
-                    if (id >= P.n_items) { exhausted = true; break; }
+                    q = (uint32_t)__builtin_amdgcn_readfirstlane((int)q);
+                    probes = (uint32_t)__builtin_amdgcn_readfirstlane((int)probes);
+                    if (id == 0xFFFFFFFFu) { exhausted = true; break; }
                     pool_item = id;
                     pool_next = 0;
                 }
@@ -382,9 +404,12 @@ __global__ void __launch_bounds__(kBlock, PT_WAVES_PER_EU) render_kernel(RenderP
                 if (!got) {
                     done = true;
                 } else {
-                    const uint32_t tile = my_item / (uint32_t)n_slices;
-                    slice = (int)(my_item - tile * (uint32_t)n_slices);
-                    const int tx = (int)(tile % (uint32_t)P.tiles_x), ty = (int)(tile / (uint32_t)P.tiles_x);
+                    /* item -> (tile in macro-tile order, slice) */
+                    const uint32_t tseq = my_item / (uint32_t)n_slices;
+                    slice = (int)(my_item - tseq * (uint32_t)n_slices);
+                    const uint32_t mt = tseq >> 6, lt = tseq & 63u;
+                    const int tx = (int)((mt % (uint32_t)P.mtiles_x) * 8u + (lt & 7u));
+                    const int ty = (int)((mt / (uint32_t)P.mtiles_x) * 8u + (lt >> 3));
                     const int px = tx * 8 + (my_slot & 7), py = ty * 8 + (my_slot >> 3);
                     if (px < W && py < H) {
                         pixel = py * W + px;
@@ -493,7 +518,7 @@ int launch_camera_rays(const pt_camera &cam, uint32_t seed, int sample, float *d
     return 0;
 }
 
-int launch_render(const RenderParams &p, int n_cu, hipStream_t stream) {
+int launch_render(RenderParams p, int n_cu, int max_queues, hipStream_t stream) {
     const size_t lds = stack_bytes(p.sc.max_depth);
     /* persistent grid: as many workgroups as stay resident (registers allow 4 waves per SIMD =
      * 4 workgroups of 256 threads per CU; LDS allows 160 KiB / lds) */
@@ -504,6 +529,8 @@ int launch_render(const RenderParams &p, int n_cu, hipStream_t stream) {
     const int64_t max_useful = ((int64_t)p.n_items * 64 + kBlock - 1) / kBlock;
     if (blocks > max_useful) blocks = max_useful;
     if (blocks < 1) blocks = 1;
+    if (blocks > max_queues) blocks = max_queues;
+    p.n_queues = (uint32_t)blocks;
     if (p.stats)
         hipLaunchKernelGGL(render_kernel<true>, dim3((unsigned)blocks), dim3(kBlock), lds, stream, p);
     else

@@ -25,12 +25,22 @@ struct PtNode {
     uint32_t b;   /* inner: 8-bit child mask;       leaf: number of records */
 };
 
+#ifndef PT_TRI_PAD64
+#define PT_TRI_PAD64 0
+#endif
+#if PT_TRI_PAD64
+struct alignas(64) PtTriRec {
+#else
 struct alignas(16) PtTriRec {
+#endif
     float v0x, v0y, v0z, e1x;
     float e1y, e1z, e2x, e2y;
     float e2z;
     int32_t id;        /* triangle index inside its entity */
     int32_t pad0, pad1;
+#if PT_TRI_PAD64
+    int32_t pad2[4];
+#endif
 };
 
 struct alignas(16) PtShadeRec {
