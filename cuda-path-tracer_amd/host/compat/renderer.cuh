@@ -1,0 +1,3 @@
+/* Source-compatibility header: the reference spreads its host API over src/renderer.cuh and others;
+ * here the whole API lives in path_tracer.h. */
+#include "../path_tracer.h"
