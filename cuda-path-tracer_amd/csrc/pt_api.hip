@@ -341,6 +341,8 @@ int pt_scene_commit(pt_scene *scene) {
                 const uint32_t rec_base = (uint32_t)recs.size();
                 e.root_node = node_base;
                 const FlatOctree &T = h.tree;
+                /* the traversal stack keeps child indices relative to the entity's root in 24 bits */
+                if (T.nodes.size() >= (1ull << 24)) PT_FAIL("pt_scene_commit: an octree has 2^24 or more nodes; lower its depth");
                 const size_t n_inner = T.nodes.size() - (size_t)T.nodes_per_depth[T.max_depth];
                 for (size_t n = 0; n < T.nodes.size(); n++) {
                     PtNode nd = T.nodes[n];

@@ -12,7 +12,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 PKG_ROOT = os.path.dirname(os.path.dirname(_HERE))
 LIB_PATH = os.environ.get("PTAMD_LIB") or os.path.join(PKG_ROOT, "lib", "libptamd.so")
-PT_MAX_OCTREE_DEPTH = 12
+PT_MAX_OCTREE_DEPTH = 10
 
 
 class PtError(RuntimeError):

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define PT_MAX_OCTREE_DEPTH 12   /* reference: fixed 6 (src/geometry.cuh:4) */
+#define PT_MAX_OCTREE_DEPTH 10   /* reference: fixed 6 (src/geometry.cuh:4); 3 path bits per level in 32 */
 
 typedef struct pt_scene pt_scene;
 
