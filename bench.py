@@ -167,7 +167,7 @@ def main():
             tc = time.perf_counter()
             osc.render(ocam, 1337, 0, 1, rows=rows, n_threads=cores)
             t1 = time.perf_counter() - tc
-            n_cpu = int(max(1, min(16, round(12.0 / max(t1, 1e-3)))))
+            n_cpu = int(max(1, min(64, round(15.0 / max(t1, 1e-3)))))
             tc = time.perf_counter()
             _, ccnt = osc.render(ocam, 1337, 1, 1 + n_cpu, rows=rows, n_threads=cores)
             tn = time.perf_counter() - tc

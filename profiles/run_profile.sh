@@ -9,8 +9,11 @@ root=${GRAFT_REPO_ROOT:-$(pwd)}
 out=$root/gpurun_out/prof_$tag
 mkdir -p $out
 cd $root
-args="--no-cpu-baseline $*"
-timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python3 bench.py $args > $out/trace_bench.json 2> $out/trace.err || { echo "trace pass failed"; tail -5 $out/trace.err; exit 1; }
+# the kernel-trace pass runs the benchmark's default command line, so its per-kernel average is
+# directly comparable with the HIP-event time in the bench line; the counter passes use a shorter
+# run of the same workload (PMC_ARGS, default 256 spp, one step)
+args="--no-cpu-baseline ${PMC_ARGS:---spp 256 --steps 1 --warmup 0}"
+timeout -s KILL 400 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python3 bench.py $* > $out/trace_bench.json 2> $out/trace.err || { echo "trace pass failed"; tail -5 $out/trace.err; exit 1; }
 pass() {
   name=$1; shift
   timeout -s KILL 300 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $out/pmc_$name -- python3 bench.py $args > $out/pmc_${name}_bench.json 2> $out/pmc_$name.err || { echo "pmc pass $name failed"; tail -5 $out/pmc_$name.err; exit 1; }
