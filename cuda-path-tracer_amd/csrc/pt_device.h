@@ -101,10 +101,9 @@ struct Lane {
     int32_t ent;             /* entity being processed (M_ENTITY: about to start it) */
     /* octree walk */
     float t0x, t0y, t0z, t1x, t1y, t1z;   /* parametric interval of the current node */
-    uint32_t nb, nm;         /* current node: index of first child, child mask */
-    uint32_t nbase;          /* entity's first node (stack words hold child indices relative to it) */
+    uint32_t nb;             /* current node: index of its first child */
+    uint32_t todo;           /* current node: its child list (see child_list) | child mask << 24 */
     uint32_t path;           /* 3 bits per level: the child slot taken at each ancestor */
-    int32_t curr;            /* next child candidate (mirrored numbering), 8 = node exhausted */
     int32_t level, maxd, a;
     /* triangle run (octree leaf or brute-force mesh) */
     uint32_t tri_cur, tri_end;
@@ -112,33 +111,51 @@ struct Lane {
     uint32_t touch;          /* first word of the NEXT record, requested one trip ahead (see leaf_block) */
 };
 
-/* dgf:116-126 with the per-child argument table of dgf:178-187 folded in: the exit parameters of
- * child `curr` are that child's t1, and the successor along an axis is curr with that axis bit
- * set, or 8 (leave the node) when the bit is already set. */
-__device__ __forceinline__ int next_child(int curr, float ex, float ey, float ez) {
-    const int cx = (curr & 4) ? 8 : (curr | 4);
-    const int cy = (curr & 2) ? 8 : (curr | 2);
-    const int cz = (curr & 1) ? 8 : (curr | 1);
-    int r = cz;
-    if (ex < ey) {
-        if (ex < ez) r = cx;
-    } else {
-        if (ey < ez) r = cy;
-    }
-    return r;
+/* dgf:95-110 (find_first_node), written with selects: the entry plane is the one with the largest
+ * t0; the answer sets the bit of every other axis whose mid plane lies before the entry point.
+ * The comparisons and their operands are the reference's. */
+__device__ __forceinline__ int first_child(float t0x, float t0y, float t0z, float tMx, float tMy, float tMz) {
+    const bool cx = (t0x > t0y) && (t0x > t0z);
+    const bool cy = !cx && (t0y > t0z);
+    const float te = cx ? t0x : (cy ? t0y : t0z);
+    const int bits = ((tMx < te) ? 4 : 0) | ((tMy < te) ? 2 : 0) | ((tMz < te) ? 1 : 0);
+    return bits & (cx ? 3 : (cy ? 5 : 6));
 }
 
-/* dgf:95-110 */
-__device__ __forceinline__ int first_child(float t0x, float t0y, float t0z, float tMx, float tMy, float tMz) {
-    int answer;
-    if (t0x > t0y && t0x > t0z) {
-        answer = ((tMy < t0x) ? 2 : 0) | ((tMz < t0x) ? 1 : 0);
-    } else if (t0y > t0z) {
-        answer = ((tMx < t0y) ? 4 : 0) | ((tMz < t0y) ? 1 : 0);
-    } else {
-        answer = ((tMx < t0z) ? 4 : 0) | ((tMy < t0z) ? 2 : 0);
+/*
+ * The children of a node that proc_subtree's loop (dgf:159-188) would step through, in order.
+ * The loop starts at find_first_node and moves on with next_node (dgf:116-126) applied to the exit
+ * parameters of the current child (per axis: the node's t1 if the child's bit is set, else tM, the
+ * argument table of dgf:178-187): the axis with the smallest exit parameter gets its bit set, or
+ * the node is left when that bit is already set.  Bits are only ever set, so the sequence has at
+ * most four members and does not depend on which children exist -- it is evaluated once, on entry:
+ *   bits  0..11  four 3-bit child numbers (mirrored numbering)
+ *   bits 12..15  go:  member i exists in the tree and passes the entry test of dgf:142
+ *   bits 16..19  rej: member i exists but fails that test (entered and left at once: it only counts)
+ *   bits 24..31  the node's child mask
+ * Members after the one that leaves the node have neither flag.
+ */
+__device__ __forceinline__ uint32_t child_list(float t0x, float t0y, float t0z, float t1x, float t1y, float t1z, uint32_t nm,
+                                               int a) {
+    const float tMx = 0.5f * (t0x + t1x), tMy = 0.5f * (t0y + t1y), tMz = 0.5f * (t0z + t1z);
+    int c = first_child(t0x, t0y, t0z, tMx, tMy, tMz);
+    uint32_t list = nm << 24;
+    bool open = true;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        /* exit parameters of child c = its t1 */
+        const float ex = (c & 4) ? t1x : tMx, ey = (c & 2) ? t1y : tMy, ez = (c & 1) ? t1z : tMz;
+        const bool present = open && ((nm >> (c ^ a)) & 1u);
+        const bool rejected = (ex < 0.0f) || (ey < 0.0f) || (ey < 0.0f);       /* dgf:142 (y twice, never z) */
+        list |= (uint32_t)c << (3 * i);
+        list |= (present ? (rejected ? 0x10000u : 0x1000u) : 0u) << i;
+        if (i < 3) {
+            const int axis = (ex < ey) ? ((ex < ez) ? 4 : 1) : ((ey < ez) ? 2 : 1);
+            open = open && !(c & axis);
+            c |= axis;
+        }
     }
-    return answer;
+    return list;
 }
 
 /* dgf:388-417 */
@@ -219,62 +236,59 @@ __device__ __forceinline__ void entity_block(const PtSceneDev &sc, Lane &L, Stat
     if ((t1x < 0.0f) || (t1y < 0.0f) || (t1y < 0.0f)) return;   /* dgf:142 (tests y twice, never z) */
     const PtNode rec = sc.nodes[e.root_node];
     L.t0x = t0x; L.t0y = t0y; L.t0z = t0z; L.t1x = t1x; L.t1y = t1y; L.t1z = t1z;
-    L.nb = rec.a; L.nm = rec.b; L.nbase = e.root_node;
+    L.nb = rec.a;
     L.a = a; L.level = 0; L.path = 0; L.maxd = e.octree_depth;
-    L.curr = first_child(t0x, t0y, t0z, 0.5f * (t0x + t1x), 0.5f * (t0y + t1y), 0.5f * (t0z + t1z));
+    L.todo = child_list(t0x, t0y, t0z, t1x, t1y, t1z, rec.b, a);
     L.mode = M_NODE;
 }
 
 /*
- * NODE block: one step of proc_subtree's child loop (dgf:159-188) at the current inner node.
- *   curr == 8            -> the node is exhausted: return to the parent (pop) or finish the walk;
- *   child curr^a absent  -> advance curr;
- *   child present        -> it is "entered" (counted); rejected by the dgf:142 test -> advance;
- *                           at leaf depth -> becomes a triangle run, curr already advanced;
- *                           otherwise -> push the frame and descend.
+ * NODE block: proc_subtree's child loop (dgf:159-188) at the current inner node, one entered child
+ * per trip.
+ *   list exhausted  -> return to the parent (pop), or finish the walk at the root; the parent's
+ *                      next child is taken in the same trip;
+ *   next member     -> the child is entered: at leaf depth it becomes a triangle run, otherwise the
+ *                      frame is pushed, the walk descends and the child's own list is built.
+ * Members that do not exist cost nothing; members that fail the entry test are counted when the
+ * walk passes over them.
  * Frames: descending, each axis of the child interval inherits one bound from the parent
- * ([t0,tM] or [tM,t1]); the stack word keeps the three bounds the child does NOT inherit and the
- * parent's {first child, mask}; the slot taken goes into `path`.  Returning, the parent's t0/t1
- * are rebuilt from the child's interval and the saved bounds by copies only, and tM is recomputed
- * by the same expression, so every value is the one the recursion would hold.
+ * ([t0,tM] or [tM,t1]); the frame keeps the three bounds the child does NOT inherit, the parent's
+ * first-child index and what is left of its list; the slot taken goes into `path`.  Returning, the
+ * parent's t0/t1 are rebuilt from the child's interval and the saved bounds by copies only, and tM
+ * is recomputed by the same expression, so every value is the one the recursion would hold.
  */
 template <bool STATS>
-__device__ __forceinline__ void node_block(const PtSceneDev &sc, Lane &L, Stats &st, float4 *stack, int stride) {
-    if (L.curr >= 8) {
+__device__ __forceinline__ void node_block(const PtSceneDev &sc, Lane &L, Stats &st, float4 *stack, uint32_t *stack1, int stride) {
+    if (((L.todo >> 12) & 0xFu) == 0u) {
+        if (STATS) st.node_visits += __popc((L.todo >> 16) & 0xFu);
         if (L.level == 0) { L.mode = M_ENTITY; return; }     /* walk finished without an accepted leaf */
         L.level--;
         const float4 s = stack[L.level * stride];
+        const uint32_t w = stack1[L.level * stride];
         const int c = (int)(L.path & 7u);
         L.path >>= 3;
-        const uint32_t w = __float_as_uint(s.w);
-        /* (t0,t1) still hold the child's interval: its t1 is the exit parameter set of slot c */
-        const float ex = L.t1x, ey = L.t1y, ez = L.t1z;
         /* value selects, not conditional stores: a store through a selected field address would
          * force the whole lane state into scratch memory */
         const float p0x = (c & 4) ? s.x : L.t0x, p1x = (c & 4) ? L.t1x : s.x;
         const float p0y = (c & 2) ? s.y : L.t0y, p1y = (c & 2) ? L.t1y : s.y;
         const float p0z = (c & 1) ? s.z : L.t0z, p1z = (c & 1) ? L.t1z : s.z;
         L.t0x = p0x; L.t1x = p1x; L.t0y = p0y; L.t1y = p1y; L.t0z = p0z; L.t1z = p1z;
-        L.nb = L.nbase + (w >> 8);
-        L.nm = w & 0xFFu;
-        L.curr = next_child(c, ex, ey, ez);
-        return;
+        L.nb = __float_as_uint(s.w);
+        L.todo = w;
+        if (((w >> 12) & 0xFu) == 0u) return;                /* the parent is exhausted as well: next trip */
     }
+    const uint32_t go = (L.todo >> 12) & 0xFu;
+    const int i = __ffs((int)go) - 1;
+    const int curr = (int)((L.todo >> (3 * i)) & 7u);
+    const uint32_t below = (1u << i) - 1u;
+    if (STATS) st.node_visits += 1 + __popc((L.todo >> 16) & below);
+    L.todo &= ~((0x1000u << i) | (below << 16));             /* consumed; passed-over rejects counted */
+    const uint32_t nm = L.todo >> 24;
     const float tMx = 0.5f * (L.t0x + L.t1x), tMy = 0.5f * (L.t0y + L.t1y), tMz = 0.5f * (L.t0z + L.t1z);
-    const int curr = L.curr;
-    /* interval of child `curr` */
-    const float c0x = (curr & 4) ? tMx : L.t0x, c1x = (curr & 4) ? L.t1x : tMx;
-    const float c0y = (curr & 2) ? tMy : L.t0y, c1y = (curr & 2) ? L.t1y : tMy;
-    const float c0z = (curr & 1) ? tMz : L.t0z, c1z = (curr & 1) ? L.t1z : tMz;
-    const int nxt = next_child(curr, c1x, c1y, c1z);
     const int adj = curr ^ L.a;
-    if (!((L.nm >> adj) & 1u)) { L.curr = nxt; return; }
-    if (STATS) st.node_visits++;
-    if ((c1x < 0.0f) || (c1y < 0.0f) || (c1y < 0.0f)) { L.curr = nxt; return; }   /* dgf:142 */
-    const uint32_t child = L.nb + (uint32_t)__popc(L.nm & ((1u << adj) - 1u));
+    const uint32_t child = L.nb + (uint32_t)__popc(nm & ((1u << adj) - 1u));
     const PtNode rec = sc.nodes[child];
     if (L.level + 1 == L.maxd) {          /* leaf: dgf:146-157 */
-        L.curr = nxt;
         if (rec.b != 0u) {
             L.tri_cur = rec.a; L.tri_end = rec.a + rec.b;
             L.run_flags = 2;
@@ -283,17 +297,22 @@ __device__ __forceinline__ void node_block(const PtSceneDev &sc, Lane &L, Stats 
         }
         return;
     }
+    /* interval of child `curr` */
+    const float c0x = (curr & 4) ? tMx : L.t0x, c1x = (curr & 4) ? L.t1x : tMx;
+    const float c0y = (curr & 2) ? tMy : L.t0y, c1y = (curr & 2) ? L.t1y : tMy;
+    const float c0z = (curr & 1) ? tMz : L.t0z, c1z = (curr & 1) ? L.t1z : tMz;
     float4 s;
     s.x = (curr & 4) ? L.t0x : L.t1x;
     s.y = (curr & 2) ? L.t0y : L.t1y;
     s.z = (curr & 1) ? L.t0z : L.t1z;
-    s.w = __uint_as_float(((L.nb - L.nbase) << 8) | L.nm);
+    s.w = __uint_as_float(L.nb);
     stack[L.level * stride] = s;
+    stack1[L.level * stride] = L.todo;
     L.path = (L.path << 3) | (uint32_t)curr;
     L.level++;
     L.t0x = c0x; L.t0y = c0y; L.t0z = c0z; L.t1x = c1x; L.t1y = c1y; L.t1z = c1z;
-    L.nb = rec.a; L.nm = rec.b;
-    L.curr = first_child(c0x, c0y, c0z, 0.5f * (c0x + c1x), 0.5f * (c0y + c1y), 0.5f * (c0z + c1z));
+    L.nb = rec.a;
+    L.todo = child_list(c0x, c0y, c0z, c1x, c1y, c1z, rec.b, L.a);
 }
 
 /*
@@ -367,8 +386,8 @@ __device__ __forceinline__ void leaf_block(const PtSceneDev &sc, Lane &L, Stats 
  * The block with the most waiting lanes runs next, for a few trips while it stays well filled.
  */
 template <bool STATS, bool LOG>
-__device__ __forceinline__ void trace_wave(const PtSceneDev &sc, Lane &L, Stats &st, TriLog &lg, float4 *stack, int stride,
-                                           int done_quota) {
+__device__ __forceinline__ void trace_wave(const PtSceneDev &sc, Lane &L, Stats &st, TriLog &lg, float4 *stack, uint32_t *stack1,
+                                           int stride, int done_quota) {
     for (;;) {
         const int n_ent = __popcll(__ballot(L.mode == M_ENTITY));
         const int n_node = __popcll(__ballot(L.mode == M_NODE));
@@ -383,7 +402,7 @@ __device__ __forceinline__ void trace_wave(const PtSceneDev &sc, Lane &L, Stats 
 #pragma nounroll
             do {
                 if (STATS) st.node_trips++;
-                if (L.mode == M_NODE) { if (STATS) st.node_lanes++; node_block<STATS>(sc, L, st, stack, stride); }
+                if (L.mode == M_NODE) { if (STATS) st.node_lanes++; node_block<STATS>(sc, L, st, stack, stack1, stride); }
             } while (++trips < PT_TRIPS && 2 * __popcll(__ballot(L.mode == M_NODE)) >= n_node);
         } else {
             int trips = 0;

@@ -18,6 +18,8 @@
 namespace ptamd {
 
 static constexpr int kBlock = 256;
+/* frames of the per-lane octree stack: one 16-byte and one 4-byte word per level, each level an array over the workgroup's lanes */
+__host__ __device__ static inline int stack_levels(int max_depth) { return max_depth > 0 ? max_depth : 1; }
 
 /* ------------------------------------------------------------------ shading (fast math allowed) */
 
@@ -217,6 +219,7 @@ __global__ void __launch_bounds__(kBlock) trace_kernel(PtSceneDev sc, const floa
                                                        unsigned long long *__restrict__ stats) {
     extern __shared__ float4 lds_stack[];
     float4 *stack = lds_stack + threadIdx.x;
+    uint32_t *stack1 = reinterpret_cast<uint32_t *>(lds_stack + stack_levels(sc.max_depth) * kBlock) + threadIdx.x;
     Stats st;
     stats_zero(st);
     Lane L;
@@ -256,7 +259,7 @@ __global__ void __launch_bounds__(kBlock) trace_kernel(PtSceneDev sc, const floa
         }
         first = false;
         if (__ballot(L.mode != M_IDLE) == 0ull) break;
-        trace_wave<true, LOG>(sc, L, st, lg, stack, kBlock, kDoneQuota);
+        trace_wave<true, LOG>(sc, L, st, lg, stack, stack1, kBlock, kDoneQuota);
     }
     if (stats) {
         flush_stat(&stats[0], st.segments);
@@ -293,6 +296,7 @@ template <bool STATS>
 __global__ void __launch_bounds__(kBlock, PT_WAVES_PER_EU) render_kernel(RenderParams P) {
     extern __shared__ float4 lds_stack[];
     float4 *stack = lds_stack + threadIdx.x;
+    uint32_t *stack1 = reinterpret_cast<uint32_t *>(lds_stack + stack_levels(P.sc.max_depth) * kBlock) + threadIdx.x;
     const int lane = threadIdx.x & 63;
     const int W = P.cam.res_x, H = P.cam.res_y;
     const int n_slices = P.plan.n_split * P.plan.slices_per_split;
@@ -435,7 +439,7 @@ __global__ void __launch_bounds__(kBlock, PT_WAVES_PER_EU) render_kernel(RenderP
             if (__ballot(!done) == 0ull) break;      /* every lane is out of work: the grid drains */
             continue;                                /* e.g. lanes that drew an out-of-image slot ask again */
         }
-        trace_wave<STATS, false>(P.sc, L, st, lg, stack, kBlock, kDoneQuota);
+        trace_wave<STATS, false>(P.sc, L, st, lg, stack, stack1, kBlock, kDoneQuota);
     }
     if (STATS && P.stats) {
         flush_stat(&P.stats[0], st.segments);
@@ -494,7 +498,7 @@ SlicePlan make_slice_plan(int sample_begin, int sample_end, int n_split) {
     return p;
 }
 
-static size_t stack_bytes(int max_depth) { return (size_t)(max_depth > 0 ? max_depth : 1) * kBlock * sizeof(float4); }
+static size_t stack_bytes(int max_depth) { return (size_t)stack_levels(max_depth) * kBlock * (sizeof(float4) + sizeof(uint32_t)); }
 
 int launch_trace(const PtSceneDev &sc, const float *d_rays, int64_t n, pt_hit *d_hits, int32_t *d_log, int log_stride,
                  unsigned long long *d_stats, hipStream_t stream) {
