@@ -77,16 +77,6 @@ struct TriLog {        /* optional per-ray record of the triangle-test sequence 
     int32_t cap;
 };
 
-/* one-trip-ahead request of the next triangle record's cache line */
-#ifndef PT_USE_TOUCH
-#define PT_USE_TOUCH 0
-#endif
-#if PT_USE_TOUCH
-#define PT_TOUCH(L, ptr) (L).touch = *reinterpret_cast<const uint32_t *>(ptr)
-#else
-#define PT_TOUCH(L, ptr) ((void)0)
-#endif
-
 #ifndef PT_TRIPS
 #define PT_TRIPS 8
 #endif
@@ -108,23 +98,12 @@ struct Lane {
     /* triangle run (octree leaf or brute-force mesh) */
     uint32_t tri_cur, tri_end;
     int32_t run_flags;       /* bit0: some test of this run was accepted, bit1: run is an octree leaf */
-    uint32_t touch;          /* first word of the NEXT record, requested one trip ahead (see leaf_block) */
 };
-
-/* dgf:95-110 (find_first_node), written with selects: the entry plane is the one with the largest
- * t0; the answer sets the bit of every other axis whose mid plane lies before the entry point.
- * The comparisons and their operands are the reference's. */
-__device__ __forceinline__ int first_child(float t0x, float t0y, float t0z, float tMx, float tMy, float tMz) {
-    const bool cx = (t0x > t0y) && (t0x > t0z);
-    const bool cy = !cx && (t0y > t0z);
-    const float te = cx ? t0x : (cy ? t0y : t0z);
-    const int bits = ((tMx < te) ? 4 : 0) | ((tMy < te) ? 2 : 0) | ((tMz < te) ? 1 : 0);
-    return bits & (cx ? 3 : (cy ? 5 : 6));
-}
 
 /*
  * The children of a node that proc_subtree's loop (dgf:159-188) would step through, in order.
- * The loop starts at find_first_node and moves on with next_node (dgf:116-126) applied to the exit
+ * The loop starts at find_first_node (dgf:95-110: the entry plane is the one with the largest t0;
+ * every other axis whose mid plane lies before the entry point has its bit set) and moves on with next_node (dgf:116-126) applied to the exit
  * parameters of the current child (per axis: the node's t1 if the child's bit is set, else tM, the
  * argument table of dgf:178-187): the axis with the smallest exit parameter gets its bit set, or
  * the node is left when that bit is already set.  Bits are only ever set, so the sequence has at
@@ -135,24 +114,37 @@ __device__ __forceinline__ int first_child(float t0x, float t0y, float t0z, floa
  *   bits 24..31  the node's child mask
  * Members after the one that leaves the node have neither flag.
  */
+template <bool STATS>
 __device__ __forceinline__ uint32_t child_list(float t0x, float t0y, float t0z, float t1x, float t1y, float t1z, uint32_t nm,
                                                int a) {
     const float tMx = 0.5f * (t0x + t1x), tMy = 0.5f * (t0y + t1y), tMz = 0.5f * (t0z + t1z);
-    int c = first_child(t0x, t0y, t0z, tMx, tMy, tMz);
-    uint32_t list = nm << 24;
+    /* find_first_node; the state of the walk is kept as one flag per axis (its bit in the child
+     * number) and that axis' exit parameter (t1 once the bit is set, tM before), so that a step is
+     * three comparisons and three selects; the flag logic is wave-uniform-style mask arithmetic */
+    const bool fx = (t0x > t0y) && (t0x > t0z);
+    const bool fy = !fx && (t0y > t0z);
+    const float te = fx ? t0x : (fy ? t0y : t0z);
+    bool bx = !fx && (tMx < te), by = (fx || !fy) && (tMy < te), bz = (fx || fy) && (tMz < te);
+    float ex = bx ? t1x : tMx, ey = by ? t1y : tMy, ez = bz ? t1z : tMz;
+    uint32_t c = (bx ? 4u : 0u) | (by ? 2u : 0u) | (bz ? 1u : 0u);
+    uint32_t list = (nm << 24) | c;
     bool open = true;
 #pragma unroll
     for (int i = 0; i < 4; i++) {
-        /* exit parameters of child c = its t1 */
-        const float ex = (c & 4) ? t1x : tMx, ey = (c & 2) ? t1y : tMy, ez = (c & 1) ? t1z : tMz;
-        const bool present = open && ((nm >> (c ^ a)) & 1u);
+        /* member i = child c, whose exit parameters are (ex, ey, ez) */
+        const uint32_t present = (nm >> (c ^ (uint32_t)a)) & 1u;
         const bool rejected = (ex < 0.0f) || (ey < 0.0f) || (ey < 0.0f);       /* dgf:142 (y twice, never z) */
-        list |= (uint32_t)c << (3 * i);
-        list |= (present ? (rejected ? 0x10000u : 0x1000u) : 0u) << i;
+        list |= ((open && !rejected) ? present : 0u) << (12 + i);
+        if (STATS) list |= ((open && rejected) ? present : 0u) << (16 + i);
         if (i < 3) {
-            const int axis = (ex < ey) ? ((ex < ez) ? 4 : 1) : ((ey < ez) ? 2 : 1);
-            open = open && !(c & axis);
-            c |= axis;
+            const bool s1 = ex < ey, s2 = ex < ez, s3 = ey < ez;              /* next_node, dgf:116-126 */
+            const bool sx = s1 && s2, sy = !s1 && s3;
+            const bool sz = !(sx || sy);
+            open = open && !((sx && bx) || (sy && by) || (sz && bz));          /* the bit is set already: the node is left */
+            bx = bx || sx; by = by || sy; bz = bz || sz;
+            ex = sx ? t1x : ex; ey = sy ? t1y : ey; ez = sz ? t1z : ez;
+            c |= sx ? 4u : (sy ? 2u : 1u);
+            list |= c << (3 * (i + 1));
         }
     }
     return list;
@@ -169,6 +161,18 @@ __device__ __forceinline__ bool slab_test(const float mn[3], const float mx[3], 
     tmin = fmaxf(tmin, fminf(tz1, tz2));
     tmax = fminf(tmax, fmaxf(tz1, tz2));
     return !(tmax < 0.0f || tmin > tmax || best_t < tmin);
+}
+
+/* after an entity has been dealt with: on to the next one, or the ray is finished */
+#ifndef PT_ENT_SHORTCUT
+#define PT_ENT_SHORTCUT 1
+#endif
+__device__ __forceinline__ int next_entity_mode(const PtSceneDev &sc, const Lane &L) {
+#if PT_ENT_SHORTCUT
+    return L.ent >= sc.n_entities ? M_DONE : M_ENTITY;
+#else
+    return M_ENTITY;
+#endif
 }
 
 __device__ __forceinline__ void lane_start_ray(Lane &L, V3 o, V3 d) {
@@ -190,7 +194,8 @@ __device__ __forceinline__ void entity_block(const PtSceneDev &sc, Lane &L, Stat
     if (L.ent >= sc.n_entities) { L.mode = M_DONE; return; }
     const PtEntity &e = sc.entities[L.ent];
     const int32_t ei = L.ent;
-    L.ent = ei + 1;                       /* default: move on to the next entity */
+    L.ent = ei + 1;                       /* default: move on to the next entity, or finish */
+    L.mode = next_entity_mode(sc, L);
     if (e.shape == PT_SHAPE_SPHERE) {     /* dgf:257-275; a sphere hit clears the triangle */
         const V3 dd = L.o - mk(e.center[0], e.center[1], e.center[2]);
         const float p1 = -dot3(L.d, dd);
@@ -213,7 +218,6 @@ __device__ __forceinline__ void entity_block(const PtSceneDev &sc, Lane &L, Stat
         L.tri_cur = e.tri_first; L.tri_end = e.tri_first + e.n_tris;
         L.run_flags = 0;
         L.mode = M_LEAF;
-        PT_TOUCH(L, sc.tris + e.tri_first);
         return;
     }
     V3 o = L.o, d = L.d;
@@ -238,7 +242,7 @@ __device__ __forceinline__ void entity_block(const PtSceneDev &sc, Lane &L, Stat
     L.t0x = t0x; L.t0y = t0y; L.t0z = t0z; L.t1x = t1x; L.t1y = t1y; L.t1z = t1z;
     L.nb = rec.a;
     L.a = a; L.level = 0; L.path = 0; L.maxd = e.octree_depth;
-    L.todo = child_list(t0x, t0y, t0z, t1x, t1y, t1z, rec.b, a);
+    L.todo = child_list<STATS>(t0x, t0y, t0z, t1x, t1y, t1z, rec.b, a);
     L.mode = M_NODE;
 }
 
@@ -261,7 +265,7 @@ template <bool STATS>
 __device__ __forceinline__ void node_block(const PtSceneDev &sc, Lane &L, Stats &st, float4 *stack, uint32_t *stack1, int stride) {
     if (((L.todo >> 12) & 0xFu) == 0u) {
         if (STATS) st.node_visits += __popc((L.todo >> 16) & 0xFu);
-        if (L.level == 0) { L.mode = M_ENTITY; return; }     /* walk finished without an accepted leaf */
+        if (L.level == 0) { L.mode = next_entity_mode(sc, L); return; }     /* walk finished without an accepted leaf */
         L.level--;
         const float4 s = stack[L.level * stride];
         const uint32_t w = stack1[L.level * stride];
@@ -293,7 +297,6 @@ __device__ __forceinline__ void node_block(const PtSceneDev &sc, Lane &L, Stats 
             L.tri_cur = rec.a; L.tri_end = rec.a + rec.b;
             L.run_flags = 2;
             L.mode = M_LEAF;
-            PT_TOUCH(L, sc.tris + rec.a);
         }
         return;
     }
@@ -312,71 +315,103 @@ __device__ __forceinline__ void node_block(const PtSceneDev &sc, Lane &L, Stats 
     L.level++;
     L.t0x = c0x; L.t0y = c0y; L.t0z = c0z; L.t1x = c1x; L.t1y = c1y; L.t1z = c1z;
     L.nb = rec.a;
-    L.todo = child_list(c0x, c0y, c0z, c1x, c1y, c1z, rec.b, L.a);
+    L.todo = child_list<STATS>(c0x, c0y, c0z, c1x, c1y, c1z, rec.b, L.a);
 }
 
 /*
- * LEAF block: one Moller-Trumbore test (dgf:319-365) on the pre-gathered record tri_cur; e1,e2
- * were formed on the host by the same fp32 subtractions the reference performs per test.
+ * LEAF block: Moller-Trumbore tests (dgf:319-365) on the pre-gathered records of the lane's run, two
+ * per trip (the last trip of an odd run tests one); e1,e2 were formed on the host by the same fp32
+ * subtractions the reference performs per test.
+ *
+ * The two tests are evaluated side by side in two-wide vectors, which the hardware executes as
+ * packed fp32 instructions (separately rounded multiplies and adds, as in the scalar code).
  *
  * The reference divides by det before any comparison.  Here the three ratios are first formed
  * with the hardware reciprocal (relative error < 3e-7): if one of them fails its test by more
  * than a 1e-5 margin, the exactly rounded value fails it too and the test is rejected without the
- * IEEE division; otherwise the exact sequence runs.  Accepted hits and every borderline case go
- * through the exact path, so the outcome is bit-identical.
+ * IEEE division; otherwise the exact sequence runs, first for the first record, then for the
+ * second, which sees the closest hit as the first one left it.  Accepted hits and every borderline
+ * case go through the exact path, so the outcome is bit-identical to testing one by one.
  *
  * When the run ends: an octree leaf that accepted a test ends the whole walk of this entity
  * (dgf:188 unwinds every level once `hit` is set); otherwise the walk resumes; a brute-force run
  * moves on to the next entity.
  */
+typedef float f2 __attribute__((ext_vector_type(2)));
+
 template <bool STATS, bool LOG>
 __device__ __forceinline__ void leaf_block(const PtSceneDev &sc, Lane &L, Stats &st, TriLog &lg) {
     const uint32_t idx = L.tri_cur;
-    const float4 *q = reinterpret_cast<const float4 *>(sc.tris + idx);
-#if PT_USE_TOUCH
-    /* the word requested on the previous trip has to have landed before this record's three loads
-     * go out: they then hit a line that is resident instead of queueing behind its pending miss */
-    asm volatile("" ::"v"(L.touch));
-#endif
-    const float4 r0 = q[0], r1 = q[1], r2 = q[2];
-    L.tri_cur = idx + 1;
-    if (L.tri_cur != L.tri_end) PT_TOUCH(L, sc.tris + idx + 1);
-    if (STATS) st.tri_tests++;
-    const int32_t id = __float_as_int(r2.y);
+    const bool two = idx + 1u != L.tri_end;
+    const uint32_t idx2 = two ? idx + 1u : idx;
+    const float4 *qa = reinterpret_cast<const float4 *>(sc.tris + idx);
+    const float4 *qb = reinterpret_cast<const float4 *>(sc.tris + idx2);
+    const float4 a0 = qa[0], a1 = qa[1], a2 = qa[2];
+    const float4 b0 = qb[0], b1 = qb[1], b2 = qb[2];
+    L.tri_cur = idx2 + 1u;
+    if (STATS) st.tri_tests += two ? 2u : 1u;
+    const int32_t id_a = __float_as_int(a2.y), id_b = __float_as_int(b2.y);
     if (LOG) {
         int n = lg.p[0]++;
-        if (n + 1 < lg.cap) lg.p[n + 1] = id;
-    }
-    const V3 v0 = mk(r0.x, r0.y, r0.z), e1 = mk(r0.w, r1.x, r1.y), e2 = mk(r1.z, r1.w, r2.x);
-    const V3 pvec = cross3(L.d, e2);
-    const float det = dot3(e1, pvec);
-    if (!(fabsf(det) < 0.000000001f)) {
-        const V3 tvec = L.o - v0;
-        const V3 qvec = cross3(tvec, e1);
-        const float un = dot3(tvec, pvec), vn = dot3(L.d, qvec), tn = dot3(e2, qvec);
-        const float ri = __builtin_amdgcn_rcpf(det);
-        const float ua = un * ri, va = vn * ri, ta = tn * ri;
-        const bool clearly_out = (ua < -0.00011f) || (ua > 1.00011f) || (va < -0.00011f) || (ua + va > 1.00012f) ||
-                                 (ta < -1e-30f) || (ta > L.best.t * 1.00001f);
-        if (!clearly_out) {
-            const float inv_det = 1.0f / det;
-            const float u = un * inv_det;
-            if (!(u < -0.0001f || u > 1.0001f)) {
-                const float v = vn * inv_det;
-                if (!(v < -0.0001f || u + v > 1.0001f)) {
-                    const float t = tn * inv_det;
-                    if (t > 0 && t < L.best.t) {
-                        L.best.t = t; L.best.bu = u; L.best.bv = v;
-                        L.best.entity = L.ent - 1; L.best.tri = id; L.best.rec = idx;
-                        L.run_flags |= 1;
-                    }
-                }
-            }
+        if (n + 1 < lg.cap) lg.p[n + 1] = id_a;
+        if (two) {
+            n = lg.p[0]++;
+            if (n + 1 < lg.cap) lg.p[n + 1] = id_b;
         }
     }
+    const f2 v0x = {a0.x, b0.x}, v0y = {a0.y, b0.y}, v0z = {a0.z, b0.z};
+    const f2 e1x = {a0.w, b0.w}, e1y = {a1.x, b1.x}, e1z = {a1.y, b1.y};
+    const f2 e2x = {a1.z, b1.z}, e2y = {a1.w, b1.w}, e2z = {a2.x, b2.x};
+    float sdx = L.d.x, sdy = L.d.y, sdz = L.d.z, sox = L.o.x, soy = L.o.y, soz = L.o.z;
+    /* keeps the six reads scalar: folded into one-element vector loads by the optimiser, they stop the
+     * lane state from being promoted to registers */
+    asm volatile("" : "+v"(sdx), "+v"(sdy), "+v"(sdz), "+v"(sox), "+v"(soy), "+v"(soz));
+    const f2 dx = {sdx, sdx}, dy = {sdy, sdy}, dz = {sdz, sdz};
+    /* pvec = d x e2 ; det = e1 . pvec */
+    const f2 px = (dy * e2z) - (dz * e2y), py = (dz * e2x) - (dx * e2z), pz = (dx * e2y) - (dy * e2x);
+    const f2 det = (e1x * px + e1y * py) + e1z * pz;
+    /* tvec = o - v0 ; qvec = tvec x e1 */
+    const f2 ox = {sox, sox}, oy = {soy, soy}, oz = {soz, soz};
+    const f2 tx = ox - v0x, ty = oy - v0y, tz = oz - v0z;
+    const f2 qx = (ty * e1z) - (tz * e1y), qy = (tz * e1x) - (tx * e1z), qz = (tx * e1y) - (ty * e1x);
+    const f2 un = (tx * px + ty * py) + tz * pz;
+    const f2 vn = (dx * qx + dy * qy) + dz * qz;
+    const f2 tn = (e2x * qx + e2y * qy) + e2z * qz;
+    const f2 ri = {__builtin_amdgcn_rcpf(det.x), __builtin_amdgcn_rcpf(det.y)};
+    const f2 ua = un * ri, va = vn * ri, ta = tn * ri;
+    const f2 uv = ua + va;
+    const float far = L.best.t * 1.00001f;
+    uint32_t pend = 0;
+    if (!(fabsf(det.x) < 0.000000001f) &&
+        !((ua.x < -0.00011f) || (ua.x > 1.00011f) || (va.x < -0.00011f) || (uv.x > 1.00012f) || (ta.x < -1e-30f) || (ta.x > far)))
+        pend = 1u;
+    if (two && !(fabsf(det.y) < 0.000000001f) &&
+        !((ua.y < -0.00011f) || (ua.y > 1.00011f) || (va.y < -0.00011f) || (uv.y > 1.00012f) || (ta.y < -1e-30f) || (ta.y > far)))
+        pend |= 2u;
+    /* the closest hit is carried in locals and written back with value selects: conditional stores
+     * into the lane state inside this loop would push the state out of registers */
+    float bt = L.best.t, bbu = L.best.bu, bbv = L.best.bv;
+    int32_t btri = L.best.tri, bent = L.best.entity;
+    uint32_t brec = L.best.rec;
+    int32_t flags = L.run_flags;
+    while (pend != 0u) {
+        const bool second = !(pend & 1u);
+        pend &= second ? ~2u : ~1u;
+        const float det_s = second ? det.y : det.x, un_s = second ? un.y : un.x, vn_s = second ? vn.y : vn.x, tn_s = second ? tn.y : tn.x;
+        const float inv_det = 1.0f / det_s;
+        const float u = un_s * inv_det, v = vn_s * inv_det, t = tn_s * inv_det;
+        const bool acc = !(u < -0.0001f || u > 1.0001f) && !(v < -0.0001f || u + v > 1.0001f) && (t > 0 && t < bt);
+        bt = acc ? t : bt; bbu = acc ? u : bbu; bbv = acc ? v : bbv;
+        bent = acc ? L.ent - 1 : bent;
+        btri = acc ? (second ? id_b : id_a) : btri;
+        brec = acc ? (second ? idx2 : idx) : brec;
+        flags = acc ? (flags | 1) : flags;
+    }
+    L.best.t = bt; L.best.bu = bbu; L.best.bv = bbv; L.best.tri = btri; L.best.entity = bent; L.best.rec = brec;
+    L.run_flags = flags;
     if (L.tri_cur == L.tri_end) {
         if ((L.run_flags & 2) && !(L.run_flags & 1)) L.mode = M_NODE;
-        else L.mode = M_ENTITY;
+        else L.mode = next_entity_mode(sc, L);
     }
 }
 
