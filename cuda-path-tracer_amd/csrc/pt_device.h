@@ -77,6 +77,9 @@ struct TriLog {        /* optional per-ray record of the triangle-test sequence 
     int32_t cap;
 };
 
+#ifndef PT_ADAPTIVE_DONE
+#define PT_ADAPTIVE_DONE 1
+#endif
 #ifndef PT_TRIPS
 #define PT_TRIPS 8
 #endif
@@ -428,7 +431,13 @@ __device__ __forceinline__ void trace_wave(const PtSceneDev &sc, Lane &L, Stats 
         const int n_node = __popcll(__ballot(L.mode == M_NODE));
         const int n_leaf = __popcll(__ballot(L.mode == M_LEAF));
         if (n_ent + n_node + n_leaf == 0) return;
-        if (__popcll(__ballot(L.mode == M_DONE)) >= done_quota) return;
+        const int n_done = __popcll(__ballot(L.mode == M_DONE));
+#if PT_ADAPTIVE_DONE
+        /* leave to shade / refill once the finished lanes are a quorum and no block has more lanes waiting */
+        if (n_done >= done_quota && n_done >= n_node && n_done >= n_leaf) return;
+#else
+        if (n_done >= done_quota) return;
+#endif
         if (n_ent >= n_node && n_ent >= n_leaf) {
             if (STATS) st.ent_trips++;
             if (L.mode == M_ENTITY) { if (STATS) st.ent_lanes++; entity_block<STATS>(sc, L, st); }

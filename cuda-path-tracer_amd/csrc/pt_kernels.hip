@@ -204,7 +204,7 @@ __device__ __forceinline__ void flush_stat(unsigned long long *dst, uint32_t v) 
 
 /* lanes that wait in M_DONE before the wave leaves the geometry blocks to shade / refill them */
 #ifndef PT_DONE_QUOTA
-#define PT_DONE_QUOTA 16
+#define PT_DONE_QUOTA 12
 #endif
 static constexpr int kDoneQuota = PT_DONE_QUOTA;
 /* minimum waves per SIMD the register allocator must leave room for */
