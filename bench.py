@@ -26,8 +26,8 @@ sys.path.insert(0, os.path.join(REPO, "cuda-path-tracer_amd", "python"))
 HBM_PEAK_GBPS = 8000.0       # MI355X HBM3E spec peak
 # algorithmic bytes per unit of traversal / shading work (what one unit must read from the scene arrays)
 B_NODE = 8                   # one flattened octree node record
-B_TRI = 48                   # one pre-gathered triangle record (v0, e1, e2, id)
-B_SHADE = 64 + 48            # per hit: one shading record (3 normals + 3 uvs) + re-read of the accepted triangle record
+B_TRI = 40                   # one pre-gathered triangle record (v0, e1, e2, id), stored two to an 80-byte pair
+B_SHADE = 64 + 24            # per hit: one shading record (3 normals + 3 uvs) + re-read of the accepted triangle's e1, e2
 B_TEXEL = 3                  # RGB8 texel (gloss: 1, counted as 3 for simplicity -> upper bound below 0.1 % of the total)
 B_ENV = 48                   # bilinear HDRI lookup: 4 texels x 12 B
 B_ENTITY = 128               # entity record + AABB per (segment, entity)

@@ -134,15 +134,27 @@ void free_device_side(pt_scene *s) {
     s->bytes_nodes = s->bytes_tris = s->bytes_shade = s->bytes_tex = s->bytes_hdri = 0;
 }
 
-PtTriRec make_record(const float *pos, const int32_t *t, int32_t id) {
-    const float *v0 = pos + 3 * (size_t)t[0], *v1 = pos + 3 * (size_t)t[1], *v2 = pos + 3 * (size_t)t[2];
-    PtTriRec r;
-    r.v0x = v0[0]; r.v0y = v0[1]; r.v0z = v0[2];
-    /* e1 = v1 - v0, e2 = v2 - v0: the subtractions of src/device_geometry_functions.cuh:332-333 */
-    r.e1x = v1[0] - v0[0]; r.e1y = v1[1] - v0[1]; r.e1z = v1[2] - v0[2];
-    r.e2x = v2[0] - v0[0]; r.e2y = v2[1] - v0[1]; r.e2z = v2[2] - v0[2];
-    r.id = id; r.pad0 = 0; r.pad1 = 0;
-    return r;
+/* appends the triangles ids[0..n) of one run as pairs; returns the index of the run's first pair */
+uint32_t append_run(std::vector<PtTriPair> &pairs, const float *pos, const int32_t *tri6, const int32_t *ids, int64_t first_id, int64_t n) {
+    const uint32_t first = (uint32_t)pairs.size();
+    for (int64_t k = 0; k < n; k += 2) {
+        PtTriPair pr;
+        for (int j = 0; j < 2; j++) {
+            const int64_t kk = (k + j < n) ? k + j : k;       /* odd tail: repeat */
+            const int32_t id = ids ? ids[kk] : (int32_t)(first_id + kk);
+            const int32_t *t = tri6 + 6 * (size_t)id;
+            const float *v0 = pos + 3 * (size_t)t[0], *v1 = pos + 3 * (size_t)t[1], *v2 = pos + 3 * (size_t)t[2];
+            for (int c = 0; c < 3; c++) {
+                pr.f[2 * c + j] = v0[c];
+                /* e1 = v1 - v0, e2 = v2 - v0: the subtractions of src/device_geometry_functions.cuh:332-333 */
+                pr.f[2 * (3 + c) + j] = v1[c] - v0[c];
+                pr.f[2 * (6 + c) + j] = v2[c] - v0[c];
+            }
+            pr.id[j] = id;
+        }
+        pairs.push_back(pr);
+    }
+    return first;
 }
 
 void counters_from(const unsigned long long h[7], pt_counters *c) {
@@ -297,7 +309,7 @@ int pt_scene_commit(pt_scene *scene) {
 
     std::vector<PtEntity> ents(scene->entities.size());
     std::vector<PtNode> nodes;
-    std::vector<PtTriRec> recs;
+    std::vector<PtTriPair> recs;
     std::vector<PtShadeRec> shade;
     int max_depth = 0;
     for (size_t i = 0; i < scene->entities.size(); i++) {
@@ -333,29 +345,25 @@ int pt_scene_commit(pt_scene *scene) {
                 shade.push_back(sr);
             }
             if (h.octree_depth == 0) {
-                e.tri_first = (uint32_t)recs.size();
+                e.tri_first = append_run(recs, h.positions.data(), h.tri.data(), nullptr, 0, nt);
                 e.n_tris = (uint32_t)nt;
-                for (int64_t t = 0; t < nt; t++) recs.push_back(make_record(h.positions.data(), &h.tri[6 * t], (int32_t)t));
             } else {
                 const uint32_t node_base = (uint32_t)nodes.size();
-                const uint32_t rec_base = (uint32_t)recs.size();
                 e.root_node = node_base;
                 const FlatOctree &T = h.tree;
-                /* the traversal stack keeps child indices relative to the entity's root in 24 bits */
-                if (T.nodes.size() >= (1ull << 24)) PT_FAIL("pt_scene_commit: an octree has 2^24 or more nodes; lower its depth");
                 const size_t n_inner = T.nodes.size() - (size_t)T.nodes_per_depth[T.max_depth];
                 for (size_t n = 0; n < T.nodes.size(); n++) {
                     PtNode nd = T.nodes[n];
-                    nd.a += (n < n_inner) ? node_base : rec_base;
+                    if (n < n_inner) nd.a += node_base;
+                    else nd.a = append_run(recs, h.positions.data(), h.tri.data(), T.leaf_tris.data() + nd.a, 0, (int64_t)nd.b);
                     nodes.push_back(nd);
                 }
-                for (int32_t t : T.leaf_tris) recs.push_back(make_record(h.positions.data(), &h.tri[6 * (size_t)t], t));
                 if (h.octree_depth > max_depth) max_depth = h.octree_depth;
             }
         }
         ents[i] = e;
     }
-    if (nodes.size() >= (1ull << 29) || recs.size() >= (1ull << 32)) PT_FAIL("pt_scene_commit: scene too large for 32-bit indices");
+    if (nodes.size() >= (1ull << 32) || recs.size() >= (1ull << 31)) PT_FAIL("pt_scene_commit: scene too large for 32-bit indices");
 
     std::vector<PtMaterial> mats(scene->materials.size());
     for (size_t i = 0; i < scene->materials.size(); i++) {

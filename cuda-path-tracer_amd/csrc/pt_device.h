@@ -69,7 +69,7 @@ struct Best {
     float t, bu, bv;
     int32_t entity;    /* -1 = none */
     int32_t tri;       /* -1 = sphere */
-    uint32_t rec;      /* index of the accepted triangle record */
+    uint32_t rec;      /* accepted triangle record: 2 * pair index + slot */
 };
 
 struct TriLog {        /* optional per-ray record of the triangle-test sequence */
@@ -99,7 +99,7 @@ struct Lane {
     uint32_t path;           /* 3 bits per level: the child slot taken at each ancestor */
     int32_t level, maxd, a;
     /* triangle run (octree leaf or brute-force mesh) */
-    uint32_t tri_cur, tri_end;
+    uint32_t tri_cur, tri_left;   /* next triangle pair of the run, triangles still to test */
     int32_t run_flags;       /* bit0: some test of this run was accepted, bit1: run is an octree leaf */
 };
 
@@ -218,7 +218,7 @@ __device__ __forceinline__ void entity_block(const PtSceneDev &sc, Lane &L, Stat
     if (!slab_test(e.aabb_min, e.aabb_max, L.o, fr, L.best.t)) return;
     if (e.octree_depth == 0) {            /* dgf:286-291 */
         if (e.n_tris == 0) return;
-        L.tri_cur = e.tri_first; L.tri_end = e.tri_first + e.n_tris;
+        L.tri_cur = e.tri_first; L.tri_left = e.n_tris;
         L.run_flags = 0;
         L.mode = M_LEAF;
         return;
@@ -297,7 +297,7 @@ __device__ __forceinline__ void node_block(const PtSceneDev &sc, Lane &L, Stats 
     const PtNode rec = sc.nodes[child];
     if (L.level + 1 == L.maxd) {          /* leaf: dgf:146-157 */
         if (rec.b != 0u) {
-            L.tri_cur = rec.a; L.tri_end = rec.a + rec.b;
+            L.tri_cur = rec.a; L.tri_left = rec.b;
             L.run_flags = 2;
             L.mode = M_LEAF;
         }
@@ -345,15 +345,13 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 template <bool STATS, bool LOG>
 __device__ __forceinline__ void leaf_block(const PtSceneDev &sc, Lane &L, Stats &st, TriLog &lg) {
     const uint32_t idx = L.tri_cur;
-    const bool two = idx + 1u != L.tri_end;
-    const uint32_t idx2 = two ? idx + 1u : idx;
-    const float4 *qa = reinterpret_cast<const float4 *>(sc.tris + idx);
-    const float4 *qb = reinterpret_cast<const float4 *>(sc.tris + idx2);
-    const float4 a0 = qa[0], a1 = qa[1], a2 = qa[2];
-    const float4 b0 = qb[0], b1 = qb[1], b2 = qb[2];
-    L.tri_cur = idx2 + 1u;
+    const bool two = L.tri_left != 1u;
+    const float4 *q = reinterpret_cast<const float4 *>(sc.tris + idx);
+    const float4 r0 = q[0], r1 = q[1], r2 = q[2], r3 = q[3], r4 = q[4];
+    L.tri_cur = idx + 1u;
+    L.tri_left -= two ? 2u : 1u;
     if (STATS) st.tri_tests += two ? 2u : 1u;
-    const int32_t id_a = __float_as_int(a2.y), id_b = __float_as_int(b2.y);
+    const int32_t id_a = __float_as_int(r4.z), id_b = __float_as_int(r4.w);
     if (LOG) {
         int n = lg.p[0]++;
         if (n + 1 < lg.cap) lg.p[n + 1] = id_a;
@@ -362,9 +360,9 @@ __device__ __forceinline__ void leaf_block(const PtSceneDev &sc, Lane &L, Stats 
             if (n + 1 < lg.cap) lg.p[n + 1] = id_b;
         }
     }
-    const f2 v0x = {a0.x, b0.x}, v0y = {a0.y, b0.y}, v0z = {a0.z, b0.z};
-    const f2 e1x = {a0.w, b0.w}, e1y = {a1.x, b1.x}, e1z = {a1.y, b1.y};
-    const f2 e2x = {a1.z, b1.z}, e2y = {a1.w, b1.w}, e2z = {a2.x, b2.x};
+    const f2 v0x = {r0.x, r0.y}, v0y = {r0.z, r0.w}, v0z = {r1.x, r1.y};
+    const f2 e1x = {r1.z, r1.w}, e1y = {r2.x, r2.y}, e1z = {r2.z, r2.w};
+    const f2 e2x = {r3.x, r3.y}, e2y = {r3.z, r3.w}, e2z = {r4.x, r4.y};
     float sdx = L.d.x, sdy = L.d.y, sdz = L.d.z, sox = L.o.x, soy = L.o.y, soz = L.o.z;
     /* keeps the six reads scalar: folded into one-element vector loads by the optimiser, they stop the
      * lane state from being promoted to registers */
@@ -407,12 +405,12 @@ __device__ __forceinline__ void leaf_block(const PtSceneDev &sc, Lane &L, Stats 
         bt = acc ? t : bt; bbu = acc ? u : bbu; bbv = acc ? v : bbv;
         bent = acc ? L.ent - 1 : bent;
         btri = acc ? (second ? id_b : id_a) : btri;
-        brec = acc ? (second ? idx2 : idx) : brec;
+        brec = acc ? (2u * idx + (second ? 1u : 0u)) : brec;
         flags = acc ? (flags | 1) : flags;
     }
     L.best.t = bt; L.best.bu = bbu; L.best.bv = bbv; L.best.tri = btri; L.best.entity = bent; L.best.rec = brec;
     L.run_flags = flags;
-    if (L.tri_cur == L.tri_end) {
+    if (L.tri_left == 0u) {
         if ((L.run_flags & 2) && !(L.run_flags & 1)) L.mode = M_NODE;
         else L.mode = next_entity_mode(sc, L);
     }
@@ -474,9 +472,8 @@ __device__ __forceinline__ void finish_hit(const PtSceneDev &sc, V3 o, V3 d, con
         sf.normal = normalized(sf.position - mk(e.center[0], e.center[1], e.center[2]));
         return;
     }
-    const float4 *q = reinterpret_cast<const float4 *>(sc.tris + best.rec);
-    const float4 r0 = q[0], r1 = q[1], r2 = q[2];
-    const V3 e1 = mk(r0.w, r1.x, r1.y), e2 = mk(r1.z, r1.w, r2.x);
+    const float *pf = sc.tris[best.rec >> 1].f + (best.rec & 1u);
+    const V3 e1 = mk(pf[6], pf[8], pf[10]), e2 = mk(pf[12], pf[14], pf[16]);
     sf.normal = normalized(cross3(e1, e2));
     if (e.has_uvs || e.smooth_shading) {
         const PtShadeRec &sh = sc.shade[e.shade_base + (uint32_t)best.tri];

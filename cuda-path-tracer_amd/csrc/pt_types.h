@@ -5,10 +5,11 @@
  *   nodes[]   8 B per octree node, breadth-first per entity, the (up to 8) children of a node
  *             stored contiguously in slot order.  inner: {first child index, child mask};
  *             leaf (depth == entity's octree depth): {first triangle record, record count}.
- *   tris[]    48 B pre-gathered triangle records {v0, e1 = v1-v0, e2 = v2-v0, id}; one run per
- *             leaf (a triangle is repeated in every leaf it overlaps, ascending id inside a leaf),
- *             or one run in index order for a mesh without octree.  Three 16-byte loads per test
- *             instead of the reference's index -> Triangle -> 3 x Vertex pointer chase
+ *   tris[]    pre-gathered triangle records {v0, e1 = v1-v0, e2 = v2-v0, id}, 40 B per triangle,
+ *             stored as 80-byte pairs (PtTriPair); one run per leaf (a triangle is repeated in
+ *             every leaf it overlaps, ascending id inside a leaf), or one run in index order for a
+ *             mesh without octree.  Five 16-byte loads per two tests instead of the reference's
+ *             index -> Triangle -> 3 x Vertex pointer chase
  *             (src/device_geometry_functions.cuh:148-154).
  *   shade[]   64 B per unique triangle {3 vertex normals, 3 uvs}: read once per accepted hit.
  */
@@ -21,26 +22,18 @@
 #define PT_SHAPE_MESH 1
 
 struct PtNode {
-    uint32_t a;   /* inner: index of first child;   leaf: index of first triangle record */
-    uint32_t b;   /* inner: 8-bit child mask;       leaf: number of records */
+    uint32_t a;   /* inner: index of first child;   leaf: index of first triangle pair */
+    uint32_t b;   /* inner: 8-bit child mask;       leaf: number of triangles */
 };
 
-#ifndef PT_TRI_PAD64
-#define PT_TRI_PAD64 0
-#endif
-#if PT_TRI_PAD64
-struct alignas(64) PtTriRec {
-#else
-struct alignas(16) PtTriRec {
-#endif
-    float v0x, v0y, v0z, e1x;
-    float e1y, e1z, e2x, e2y;
-    float e2z;
-    int32_t id;        /* triangle index inside its entity */
-    int32_t pad0, pad1;
-#if PT_TRI_PAD64
-    int32_t pad2[4];
-#endif
+/* Two triangles side by side, component-interleaved: f[2*k + j] is component k of triangle j
+ * (k = 0..8: v0.xyz, e1.xyz, e2.xyz), so that one 16-byte load yields operand pairs for the packed
+ * two-wide arithmetic of the triangle test.  A run of n triangles (one octree leaf, or a whole mesh
+ * without octree) occupies ceil(n/2) consecutive pairs; the second half of an odd run's last pair
+ * repeats the first and is never tested. */
+struct alignas(16) PtTriPair {
+    float   f[18];
+    int32_t id[2];             /* triangle index inside its entity */
 };
 
 struct alignas(16) PtShadeRec {
@@ -55,9 +48,9 @@ struct alignas(16) PtEntity {
     int32_t  octree_depth;     /* 0 = brute force */
     uint32_t root_node;        /* index into nodes[] */
     float    aabb_min[3];
-    uint32_t tri_first;        /* brute force: first record */
+    uint32_t tri_first;        /* brute force: first triangle pair */
     float    aabb_max[3];
-    uint32_t n_tris;           /* brute force: number of records */
+    uint32_t n_tris;           /* brute force: number of triangles */
     float    region_min[3];    /* octree root region (the entity AABB when the octree was built) */
     uint32_t shade_base;
     float    region_max[3];
@@ -83,7 +76,7 @@ struct PtMaterial {
 struct PtSceneDev {
     const PtEntity   *entities;
     const PtNode     *nodes;
-    const PtTriRec   *tris;
+    const PtTriPair  *tris;
     const PtShadeRec *shade;
     const PtMaterial *materials;
     const float      *hdri;    /* h x w x 3 */
