@@ -285,7 +285,7 @@ __device__ __forceinline__ void node_block(const PtSceneDev &sc, Lane &L, Stats 
         if (((w >> 12) & 0xFu) == 0u) return;                /* the parent is exhausted as well: next trip */
     }
     const uint32_t go = (L.todo >> 12) & 0xFu;
-    const int i = __ffs((int)go) - 1;
+    const int i = __builtin_ctz(go);                          /* go != 0 here */
     const int curr = (int)((L.todo >> (3 * i)) & 7u);
     const uint32_t below = (1u << i) - 1u;
     if (STATS) st.node_visits += 1 + __popc((L.todo >> 16) & below);

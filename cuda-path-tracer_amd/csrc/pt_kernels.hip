@@ -51,12 +51,13 @@ __device__ __forceinline__ V3 tex_rgb(const uint8_t *data, int w, int h, float u
     const int x = to_index(u * (float)w, w);
     const int y = to_index((1.0f - v) * (float)h, h);
     const uint8_t *p = data + 3 * ((size_t)y * (size_t)w + (size_t)x);
-    return mk((float)p[0] / 255.0f, (float)p[1] / 255.0f, (float)p[2] / 255.0f);
+    const float k = 1.0f / 255.0f;
+    return mk((float)p[0] * k, (float)p[1] * k, (float)p[2] * k);
 }
 __device__ __forceinline__ float tex_gray(const uint8_t *data, int w, int h, float u, float v) {
     const int x = to_index(u * (float)w, w);
     const int y = to_index((1.0f - v) * (float)h, h);
-    return (float)data[(size_t)y * (size_t)w + (size_t)x] / 255.0f;
+    return (float)data[(size_t)y * (size_t)w + (size_t)x] * (1.0f / 255.0f);
 }
 
 /* src/scene.cuh:36-82 */
@@ -65,12 +66,12 @@ __device__ __forceinline__ V3 sample_hdri(const PtSceneDev &sc, V3 v, Stats &st)
     if (!sc.has_hdri) return mk(0.f, 0.f, 0.f);
     if (STATS) st.env_lookups++;
     const int W = sc.hdri_w, H = sc.hdri_h;
-    const float rn = rsqrt_ieee(v.x * v.x + 0.0f + v.z * v.z);
+    const float rn = fast_rsq(v.x * v.x + v.z * v.z);
     const float vpx = v.x * rn, vpz = v.z * rn;
-    float x_c = ((acosf(vpz) * ((__float_as_uint(vpx) >> 31) ? -1.0f : 1.0f)) / (2.0f * 3.14159265f)) + 0.5f;
-    const float y_c = fminf(1.0f - ((v.y + 1.0f) / 2.0f), 0.99f);
+    float x_c = ((acosf(vpz) * ((__float_as_uint(vpx) >> 31) ? -1.0f : 1.0f)) * (1.0f / (2.0f * 3.14159265f))) + 0.5f;
+    const float y_c = fminf(1.0f - ((v.y + 1.0f) * 0.5f), 0.99f);
     x_c += sc.hdri_rot_offset;
-    x_c = fmodf(x_c, 1.0f);
+    x_c = __builtin_amdgcn_fractf(x_c);      /* fmodf(x, 1) for x >= 0: both are exact */
     const float *cols = sc.hdri;
     V3 res;
     if (!sc.use_smooth_hdri) {
@@ -174,8 +175,9 @@ __device__ __forceinline__ void shade_hit(const PtSceneDev &sc, const Best &best
     float spec_chance = luminosity(specular);
     float diff_chance = luminosity(albedo);
     const float sum = spec_chance + diff_chance;
-    spec_chance /= sum;
-    diff_chance /= sum;
+    const float rsum = fast_rcp(sum);
+    spec_chance *= rsum;
+    diff_chance *= rsum;
     const float roulette = xi[0];
     o = sf.position + 0.001f * normal;
     if (roulette < spec_chance) {
@@ -183,13 +185,13 @@ __device__ __forceinline__ void shade_hit(const PtSceneDev &sc, const Best &best
         const float dn = dot3(d, normal);
         const V3 refl = d - (2.0f * dn) * normal;                                                   /* renderer.cu:147-149 */
         d = sample_hemisphere(refl, alpha, xi[1], xi[2]);
-        const float f = (alpha + 2.0f) / (alpha + 1.0f);
-        const float k = (1.0f / spec_chance) * f * dot3(normal, d);
+        const float f = (alpha + 2.0f) * fast_rcp(alpha + 1.0f);
+        const float k = fast_rcp(spec_chance) * f * dot3(normal, d);
         atten = mk(atten.x * specular.x * k, atten.y * specular.y * k, atten.z * specular.z * k);
     } else {
         result = result + emission * (albedo * atten);
         d = sample_hemisphere(normal, 1.0f, xi[1], xi[2]);
-        const float k = 1.0f / diff_chance;
+        const float k = fast_rcp(diff_chance);
         atten = mk(atten.x * albedo.x * k, atten.y * albedo.y * k, atten.z * albedo.z * k);
     }
 }
