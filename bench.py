@@ -45,7 +45,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="hcandersen", choices=["hcandersen", "teapot", "cornellbox", "dragon"])
+    ap.add_argument("--workload", default="hcandersen", choices=["hcandersen", "teapot", "cornellbox", "dragon", "synthetic"])
     ap.add_argument("--spp", type=int, default=0, help="override samples per pixel (default: the config's)")
     ap.add_argument("--res", type=str, default="", help="override resolution WxH")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -140,8 +140,19 @@ def main():
     k_ms = float(np.mean(kernel_ms)) if kernel_ms else float("nan")
     alg_bytes = algorithmic_bytes(counters, n_pixels, plan_slices, n_entities)
     achieved = alg_bytes / (k_ms / 1000.0) / 1e9 if k_ms > 0 else 0.0
+    # memory-side bytes per launch come from a PMC pass (rocprofv3 cannot run inside this process): the committed
+    # measurement of this exact workload is reported when there is one, otherwise null
+    traffic, traffic_source = None, None
+    workload_name = f"{args.workload} {res[0]}x{res[1]} {spp}spp octree-depth-{max(e.get('octree_depth', 0) for e in desc['entities'] if e['kind'] == 'mesh')}"
+    try:
+        with open(os.path.join(REPO, "profiles", "r1", "traffic.json")) as f:
+            tj = json.load(f)
+        if tj.get("workload") == workload_name and world == 1:
+            traffic, traffic_source = int(tj["traffic_bytes_per_launch"]), "profiles/r1/traffic.json"
+    except (OSError, ValueError, KeyError):
+        pass
     roofline = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": None,
+                "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic, "traffic_source": traffic_source,
                 "kernel": "render_kernel", "kernel_ms": round(k_ms, 3), "algorithmic_bytes_per_launch": int(alg_bytes)}
 
     cpu_baseline = None
@@ -180,7 +191,7 @@ def main():
             "value": round(value, 3), "unit": "Mpaths/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{args.workload} {res[0]}x{res[1]} {spp}spp octree-depth-{max(e.get('octree_depth', 0) for e in desc['entities'] if e['kind'] == 'mesh')}",
+            "config": {"workload": workload_name,
                        "triangles": int(sum(len(e["tri"]) for e in desc["entities"] if e["kind"] == "mesh")),
                        "spp": spp, "samples_per_rank": s_end - s_begin, "parallelism": f"sample-shard x{world}"},
             "time_to_spp_s": round(ms_per_step / 1000.0, 4),

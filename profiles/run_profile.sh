@@ -21,6 +21,14 @@ pass() {
 pass sq1 SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_INSTS_SALU SQ_WAIT_INST_ANY
 pass sq2 SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_SMEM
 pass tcc1 FETCH_SIZE TCC_HIT_sum
+# memory-side traffic of the benchmark's own default launch (for roofline.traffic): FETCH_SIZE and WRITE_SIZE
+# cannot share a pass
+if [ -n "$FULL_TRAFFIC" ]; then
+  args="--no-cpu-baseline --steps 1 --warmup 0"
+  pass full_fetch FETCH_SIZE
+  pass full_write WRITE_SIZE
+  args="--no-cpu-baseline ${PMC_ARGS:---spp 256 --steps 1 --warmup 0}"
+fi
 pass tcc2 WRITE_SIZE TCC_MISS_sum TCC_REQ_sum
 pass tcp TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum GRBM_GUI_ACTIVE
 echo "profile passes done: $out"
