@@ -107,6 +107,30 @@ def test_uv_mapped_smooth_mesh_and_depths(pt, oracle, scenes):
         g.close()
 
 
+def test_odd_runs_and_pair_tails(pt, oracle):
+    """Triangle soups with 1, 3, 5, 7 and 64 triangles, without octree (one run over the whole mesh)
+    and with shallow octrees (leaf runs of every parity): the last, half-filled pair of an odd run must
+    never be tested, and the order of tests inside a pair is the order of the run."""
+    rng = np.random.default_rng(77)
+    for n_tris in (1, 3, 5, 7, 64):
+        pos = (rng.random((3 * n_tris, 3)) * 10.0).astype(np.float32)
+        tri = np.concatenate([np.arange(3 * n_tris, dtype=np.int32).reshape(-1, 3), np.full((n_tris, 3), -1, np.int32)], axis=1)
+        rays = _random_rays(rng, 3000, np.array([5.0, 5.0, 5.0]), 6.0)
+        for depth in (0, 1, 2):
+            g = pt.Scene(0)
+            g.add_mesh(pos, tri, g.add_material(), octree_depth=depth)
+            g.commit()
+            c = oracle.OracleScene()
+            c.add_mesh(pos, tri, c.add_material(), octree_depth=depth)
+            hg, lg, cg = g.trace(rays, log_stride=80)
+            hc, lc, cc = c.trace(rays, log_stride=80)
+            _assert_hits_equal(hg, hc)
+            assert np.array_equal(lg, lc), (n_tris, depth)
+            for k in ("segments", "aabb_tests", "node_visits", "tri_tests"):
+                assert cg[k] == cc[k], (n_tris, depth, k)
+            g.close()
+
+
 def test_empty_and_device_resident_buffers(teapot_pair, pt):
     g, c, desc = teapot_pair
     hits, _, cnt = g.trace(np.zeros((0, 6), np.float32))
