@@ -19,8 +19,12 @@
  * and the wave repeatedly runs the block (entity set-up, octree node step, triangle test) that the
  * most lanes are waiting for.  One trip of a block is the same short instruction sequence for all
  * participating lanes, so divergence is bounded by the mix of states, not by the shape of each
- * lane's recursion.  The recursion's frames live in a per-lane stack of one 16-byte word per level
- * in LDS plus three bits per level in a register.
+ * lane's recursion.  The recursion's frames live in a per-lane stack of one 16-byte and one 4-byte
+ * word per level in LDS plus three bits per level in a register.
+ *
+ * The kernel is bound by vector-instruction issue (a SIMD issues one wave64 VALU instruction per four
+ * cycles), so the blocks are written for instruction count: the children a node's loop would step
+ * through are listed once per node, branch-free; triangle tests run two at a time in packed fp32.
  */
 #ifndef PT_DEVICE_H
 #define PT_DEVICE_H
@@ -77,9 +81,6 @@ struct TriLog {        /* optional per-ray record of the triangle-test sequence 
     int32_t cap;
 };
 
-#ifndef PT_ADAPTIVE_DONE
-#define PT_ADAPTIVE_DONE 1
-#endif
 #ifndef PT_TRIPS
 #define PT_TRIPS 8
 #endif
@@ -167,15 +168,8 @@ __device__ __forceinline__ bool slab_test(const float mn[3], const float mx[3], 
 }
 
 /* after an entity has been dealt with: on to the next one, or the ray is finished */
-#ifndef PT_ENT_SHORTCUT
-#define PT_ENT_SHORTCUT 1
-#endif
 __device__ __forceinline__ int next_entity_mode(const PtSceneDev &sc, const Lane &L) {
-#if PT_ENT_SHORTCUT
     return L.ent >= sc.n_entities ? M_DONE : M_ENTITY;
-#else
-    return M_ENTITY;
-#endif
 }
 
 __device__ __forceinline__ void lane_start_ray(Lane &L, V3 o, V3 d) {
@@ -429,13 +423,9 @@ __device__ __forceinline__ void trace_wave(const PtSceneDev &sc, Lane &L, Stats 
         const int n_node = __popcll(__ballot(L.mode == M_NODE));
         const int n_leaf = __popcll(__ballot(L.mode == M_LEAF));
         if (n_ent + n_node + n_leaf == 0) return;
-        const int n_done = __popcll(__ballot(L.mode == M_DONE));
-#if PT_ADAPTIVE_DONE
         /* leave to shade / refill once the finished lanes are a quorum and no block has more lanes waiting */
+        const int n_done = __popcll(__ballot(L.mode == M_DONE));
         if (n_done >= done_quota && n_done >= n_node && n_done >= n_leaf) return;
-#else
-        if (n_done >= done_quota) return;
-#endif
         if (n_ent >= n_node && n_ent >= n_leaf) {
             if (STATS) st.ent_trips++;
             if (L.mode == M_ENTITY) { if (STATS) st.ent_lanes++; entity_block<STATS>(sc, L, st); }

@@ -204,7 +204,7 @@ __device__ __forceinline__ void flush_stat(unsigned long long *dst, uint32_t v) 
     if ((threadIdx.x & 63) == 0) atomicAdd(dst, x);
 }
 
-/* lanes that wait in M_DONE before the wave leaves the geometry blocks to shade / refill them */
+/* least number of finished lanes (M_DONE) for which the wave leaves the geometry blocks to shade / refill them */
 #ifndef PT_DONE_QUOTA
 #define PT_DONE_QUOTA 12
 #endif
@@ -526,8 +526,8 @@ int launch_camera_rays(const pt_camera &cam, uint32_t seed, int sample, float *d
 
 int launch_render(RenderParams p, int n_cu, int max_queues, hipStream_t stream) {
     const size_t lds = stack_bytes(p.sc.max_depth);
-    /* persistent grid: as many workgroups as stay resident (registers allow 4 waves per SIMD =
-     * 4 workgroups of 256 threads per CU; LDS allows 160 KiB / lds) */
+    /* persistent grid: as many workgroups as stay resident (registers: PT_WAVES_PER_EU waves per SIMD =
+     * as many workgroups of 256 threads per CU; LDS: 160 KiB / lds) */
     int per_cu = PT_WAVES_PER_EU;
     const int by_lds = (int)((160 * 1024) / (lds ? lds : 1));
     if (by_lds < per_cu) per_cu = by_lds > 0 ? by_lds : 1;

@@ -184,9 +184,27 @@ Texture::~Texture() {
     if (this->data != nullptr) free(this->data);
 }
 
+Texture::Texture(const Texture &other) { *this = other; }
+
+Texture &Texture::operator=(const Texture &other) {
+    if (this == &other) return *this;
+    if (this->data) { free(this->data); this->data = nullptr; }
+    this->resolution = other.resolution;
+    if (other.data) {
+        /* the channel count is not stored: copy what the allocation holds (3 bytes per texel at most) */
+        const size_t texels = (size_t)other.resolution.x * other.resolution.y;
+        const size_t bytes = texels * (size_t)other.channels;
+        this->data = (unsigned char *)malloc(bytes);
+        memcpy(this->data, other.data, bytes);
+    }
+    this->channels = other.channels;
+    return *this;
+}
+
 void ColorTexture::set(const std::string &path) {
     if (this->data) { free(this->data); this->data = nullptr; }
     this->data = load_pnm(path, 3, this->resolution);     /* nullptr when unreadable: is_set() stays false */
+    this->channels = 3;
 }
 void ColorTexture::set(const unsigned char *rgb, ivec2 res) {
     if (this->data) free(this->data);
@@ -194,10 +212,12 @@ void ColorTexture::set(const unsigned char *rgb, ivec2 res) {
     this->data = (unsigned char *)malloc(n);
     memcpy(this->data, rgb, n);
     this->resolution = res;
+    this->channels = 3;
 }
 void GrayscaleTexture::set(const std::string &path) {
     if (this->data) { free(this->data); this->data = nullptr; }
     this->data = load_pnm(path, 1, this->resolution);
+    this->channels = 1;
 }
 void GrayscaleTexture::set(const unsigned char *gray, ivec2 res) {
     if (this->data) free(this->data);
@@ -205,6 +225,7 @@ void GrayscaleTexture::set(const unsigned char *gray, ivec2 res) {
     this->data = (unsigned char *)malloc(n);
     memcpy(this->data, gray, n);
     this->resolution = res;
+    this->channels = 1;
 }
 
 /* ================================================================== geometry */

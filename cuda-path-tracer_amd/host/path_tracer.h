@@ -69,11 +69,14 @@ struct Image {
 /* ------------------------------------------------------------------ textures / material */
 struct Texture {
     Texture() {}
+    Texture(const Texture &other);                   /* deep copies: a Material can be copied safely */
+    Texture &operator=(const Texture &other);
     ~Texture();
     void free_from_device() {}                       /* device copies are owned by the scene */
     bool is_set() const { return this->data != nullptr; }
     unsigned char *data = nullptr;                   /* 8-bit texels, row 0 first */
     ivec2 resolution = ivec2(0, 0);
+    int channels = 0;                                /* bytes per texel of `data` */
 };
 
 struct ColorTexture : Texture {
