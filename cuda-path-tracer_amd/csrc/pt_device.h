@@ -84,6 +84,13 @@ struct TriLog {        /* optional per-ray record of the triangle-test sequence 
 #ifndef PT_TRIPS
 #define PT_TRIPS 8
 #endif
+/* a block keeps running while at least 1/PT_KEEP of the lanes it started with still wait for it */
+#ifndef PT_KEEP_NODE
+#define PT_KEEP_NODE 2
+#endif
+#ifndef PT_KEEP_LEAF
+#define PT_KEEP_LEAF 2
+#endif
 
 enum : int { M_ENTITY = 0, M_NODE = 1, M_LEAF = 2, M_DONE = 3, M_IDLE = 4 };
 
@@ -435,14 +442,14 @@ __device__ __forceinline__ void trace_wave(const PtSceneDev &sc, Lane &L, Stats 
             do {
                 if (STATS) st.node_trips++;
                 if (L.mode == M_NODE) { if (STATS) st.node_lanes++; node_block<STATS>(sc, L, st, stack, stack1, stride); }
-            } while (++trips < PT_TRIPS && 2 * __popcll(__ballot(L.mode == M_NODE)) >= n_node);
+            } while (++trips < PT_TRIPS && PT_KEEP_NODE * __popcll(__ballot(L.mode == M_NODE)) >= n_node);
         } else {
             int trips = 0;
 #pragma nounroll
             do {
                 if (STATS) st.leaf_trips++;
                 if (L.mode == M_LEAF) { if (STATS) st.leaf_lanes++; leaf_block<STATS, LOG>(sc, L, st, lg); }
-            } while (++trips < PT_TRIPS && 2 * __popcll(__ballot(L.mode == M_LEAF)) >= n_leaf);
+            } while (++trips < PT_TRIPS && PT_KEEP_LEAF * __popcll(__ballot(L.mode == M_LEAF)) >= n_leaf);
         }
     }
 }
