@@ -6,6 +6,7 @@
 #include <cfloat>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <string>
@@ -64,6 +65,7 @@ struct pt_scene {
     bool has_hdri = false, hdri_smooth = false;
 
     bool committed = false;
+    bool heavy = false;        /* traversal-dominated scene: render with the many-waves build of the kernel */
     PtSceneDev dev{};
     std::vector<void *> allocs;
     uint64_t bytes_nodes = 0, bytes_tris = 0, bytes_shade = 0, bytes_tex = 0, bytes_hdri = 0;
@@ -405,6 +407,14 @@ int pt_scene_commit(pt_scene *scene) {
     d.hdri_rot_offset = scene->hdri_rot;
     d.max_depth = max_depth;
     scene->dev = d;
+    /* which build of the render kernel: scenes with a large octree spend their time in the walk and
+     * the triangle tests (measured cross-over between 24 k and 128 k triangle pairs); PTAMD_KERNEL =
+     * heavy | light overrides */
+    scene->heavy = max_depth > 0 && recs.size() >= 65536;
+    if (const char *k = getenv("PTAMD_KERNEL")) {
+        if (!strcmp(k, "heavy")) scene->heavy = true;
+        else if (!strcmp(k, "light")) scene->heavy = false;
+    }
 
     PT_HIP(hipMalloc((void **)&scene->d_tickets, kMaxQueues * sizeof(uint32_t)));
     PT_HIP(hipMalloc((void **)&scene->d_stats, 16 * sizeof(unsigned long long)));
@@ -576,7 +586,7 @@ int pt_render_accumulate(pt_scene *scene, const pt_camera *camera, uint32_t seed
         }
         PT_HIP(hipEventRecord(scene->ev_start, stream));
     }
-    if (launch_render(p, scene->n_cu, kMaxQueues, stream)) return 1;
+    if (launch_render(p, scene->n_cu, kMaxQueues, scene->heavy, stream)) return 1;
     if (scene->profiling) {
         PT_HIP(hipEventRecord(scene->ev_stop, stream));
         scene->ev_valid = true;

@@ -18,8 +18,9 @@
 namespace ptamd {
 
 static constexpr int kBlock = 256;
-/* frames of the per-lane octree stack: one 16-byte and one 4-byte word per level, each level an array over the workgroup's lanes */
-__host__ __device__ static inline int stack_levels(int max_depth) { return max_depth > 0 ? max_depth : 1; }
+/* frames of the per-lane octree stack: one 16-byte and one 4-byte word per level, each level an array over the
+ * workgroup's lanes; the walk pushes at levels 0 .. depth-2 (children of level depth-1 nodes are leaves) */
+__host__ __device__ static inline int stack_levels(int max_depth) { return max_depth > 1 ? max_depth - 1 : 1; }
 
 /* ------------------------------------------------------------------ shading (fast math allowed) */
 
@@ -209,10 +210,10 @@ __device__ __forceinline__ void flush_stat(unsigned long long *dst, uint32_t v) 
 #define PT_DONE_QUOTA 12
 #endif
 static constexpr int kDoneQuota = PT_DONE_QUOTA;
-/* minimum waves per SIMD the register allocator must leave room for */
-#ifndef PT_WAVES_PER_EU
-#define PT_WAVES_PER_EU 3
-#endif
+/* The render kernel is built twice: for 6 waves per SIMD (80 registers; the octree walk and the
+ * triangle test fit, shading spills) and for 4 (128 registers, almost no spills).  Scenes dominated by
+ * traversal gain from the extra waves, scenes dominated by entity set-up and shading lose. */
+static constexpr int kWavesHeavy = 6, kWavesLight = 4;
 
 /* ------------------------------------------------------------------ closest-hit query kernel */
 template <bool LOG>
@@ -294,8 +295,8 @@ __device__ __forceinline__ void slice_range(const SlicePlan &pl, int slice, int 
     s1 = zb + (int)((M * (j + 1)) / pl.slices_per_split);
 }
 
-template <bool STATS>
-__global__ void __launch_bounds__(kBlock, PT_WAVES_PER_EU) render_kernel(RenderParams P) {
+template <bool STATS, int WAVES>
+__global__ void __launch_bounds__(kBlock, WAVES) render_kernel(RenderParams P) {
     extern __shared__ float4 lds_stack[];
     float4 *stack = lds_stack + threadIdx.x;
     uint32_t *stack1 = reinterpret_cast<uint32_t *>(lds_stack + stack_levels(P.sc.max_depth) * kBlock) + threadIdx.x;
@@ -524,11 +525,11 @@ int launch_camera_rays(const pt_camera &cam, uint32_t seed, int sample, float *d
     return 0;
 }
 
-int launch_render(RenderParams p, int n_cu, int max_queues, hipStream_t stream) {
+int launch_render(RenderParams p, int n_cu, int max_queues, bool heavy, hipStream_t stream) {
     const size_t lds = stack_bytes(p.sc.max_depth);
-    /* persistent grid: as many workgroups as stay resident (registers: PT_WAVES_PER_EU waves per SIMD =
-     * as many workgroups of 256 threads per CU; LDS: 160 KiB / lds) */
-    int per_cu = PT_WAVES_PER_EU;
+    /* persistent grid: as many workgroups as stay resident (registers: `waves` waves per SIMD = as many
+     * workgroups of 256 threads per CU; LDS: 160 KiB / lds) */
+    int per_cu = heavy ? kWavesHeavy : kWavesLight;
     const int by_lds = (int)((160 * 1024) / (lds ? lds : 1));
     if (by_lds < per_cu) per_cu = by_lds > 0 ? by_lds : 1;
     int64_t blocks = (int64_t)n_cu * per_cu;
@@ -537,10 +538,14 @@ int launch_render(RenderParams p, int n_cu, int max_queues, hipStream_t stream) 
     if (blocks < 1) blocks = 1;
     if (blocks > max_queues) blocks = max_queues;
     p.n_queues = (uint32_t)blocks;
-    if (p.stats)
-        hipLaunchKernelGGL(render_kernel<true>, dim3((unsigned)blocks), dim3(kBlock), lds, stream, p);
-    else
-        hipLaunchKernelGGL(render_kernel<false>, dim3((unsigned)blocks), dim3(kBlock), lds, stream, p);
+    const dim3 grid((unsigned)blocks), block(kBlock);
+    if (heavy) {
+        if (p.stats) hipLaunchKernelGGL((render_kernel<true, kWavesHeavy>), grid, block, lds, stream, p);
+        else hipLaunchKernelGGL((render_kernel<false, kWavesHeavy>), grid, block, lds, stream, p);
+    } else {
+        if (p.stats) hipLaunchKernelGGL((render_kernel<true, kWavesLight>), grid, block, lds, stream, p);
+        else hipLaunchKernelGGL((render_kernel<false, kWavesLight>), grid, block, lds, stream, p);
+    }
     PT_HIP(hipGetLastError());
     return 0;
 }

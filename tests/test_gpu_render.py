@@ -86,6 +86,21 @@ def test_render_is_reproducible_and_shardable(pt, scenes):
     g.close()
 
 
+def test_both_kernel_builds_give_identical_images(pt, scenes, monkeypatch):
+    """The render kernel exists in two register budgets (chosen per scene at commit, PTAMD_KERNEL
+    overrides): same arithmetic, same summation order -> identical bits, counters included."""
+    desc = scenes.hcandersen_scene(res=(96, 54), n_tris=6000, tex_res=128, hdri_res=(128, 64))
+    out = {}
+    for build in ("light", "heavy"):
+        monkeypatch.setenv("PTAMD_KERNEL", build)
+        g, cam = pt.scene_from_description(desc)
+        out[build] = pt.render_image(g, cam, 32, seed=3, want_counters=True)
+        g.close()
+    assert np.array_equal(out["light"][0].view(np.uint32), out["heavy"][0].view(np.uint32))
+    assert out["light"][1] == out["heavy"][1]
+    assert out["light"][0].max() > 0
+
+
 def test_render_edge_cases(pt, scenes):
     desc = scenes.cornellbox_scene(res=(40, 24))
     g, cam = pt.scene_from_description(desc)
