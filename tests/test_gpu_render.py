@@ -86,6 +86,29 @@ def test_render_is_reproducible_and_shardable(pt, scenes):
     g.close()
 
 
+def test_simulated_ranks_equal_single_gpu(pt, scenes):
+    """Multi-GPU without a cluster: the per-rank sample shards of world sizes 2, 4 and 8, rendered one
+    after the other on this GPU and summed in rank order (what the sum-reduce does), reproduce the
+    single-GPU image up to fp32 association; every (pixel, sample) is drawn exactly once."""
+    from ptamd import dist as ptdist
+
+    desc = scenes.teapot_scene(res=(80, 45))
+    g, cam = pt.scene_from_description(desc)
+    spp = 64
+    whole, cnt_whole = pt.render_image(g, cam, spp, seed=11, want_counters=True)
+    for world in (2, 4, 8):
+        total = np.zeros_like(whole)
+        paths = 0
+        for rank in range(world):
+            b, e = ptdist.shard_samples(spp, rank, world)
+            part, cnt = pt.render_image(g, cam, e - b, seed=11, sample_begin=b, want_counters=True)
+            total += part
+            paths += cnt["paths"]
+        assert paths == cnt_whole["paths"]
+        assert np.allclose(total, whole, rtol=2e-5, atol=1e-5), world
+    g.close()
+
+
 def test_both_kernel_builds_give_identical_images(pt, scenes, monkeypatch):
     """The render kernel exists in two register budgets (chosen per scene at commit, PTAMD_KERNEL
     overrides): same arithmetic, same summation order -> identical bits, counters included."""
