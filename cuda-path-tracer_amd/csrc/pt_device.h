@@ -143,8 +143,10 @@ __device__ __forceinline__ uint32_t child_list(float t0x, float t0y, float t0z, 
 #pragma unroll
     for (int i = 0; i < 4; i++) {
         /* member i = child c, whose exit parameters are (ex, ey, ez) */
-        const uint32_t present = (nm >> (c ^ (uint32_t)a)) & 1u;
-        const bool rejected = (ex < 0.0f) || (ey < 0.0f) || (ey < 0.0f);       /* dgf:142 (y twice, never z) */
+        const uint32_t present = __builtin_amdgcn_ubfe(nm, c ^ (uint32_t)a, 1u);
+        /* dgf:142, (ex < 0 || ey < 0 || ey < 0): y twice, never z.  The parameters are products of finite
+         * differences and clamped reciprocals, never NaN, so "negative" is "bit pattern above -0.0" */
+        const bool rejected = max(__float_as_uint(ex), __float_as_uint(ey)) > 0x80000000u;
         list |= ((open && !rejected) ? present : 0u) << (12 + i);
         if (STATS) list |= ((open && rejected) ? present : 0u) << (16 + i);
         if (i < 3) {
