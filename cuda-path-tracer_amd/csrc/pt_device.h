@@ -151,8 +151,10 @@ __device__ __forceinline__ uint32_t child_list(float t0x, float t0y, float t0z, 
         if (STATS) list |= ((open && rejected) ? present : 0u) << (16 + i);
         if (i < 3) {
             const bool s1 = ex < ey, s2 = ex < ez, s3 = ey < ez;              /* next_node, dgf:116-126 */
+            /* x wins with ex < ey and ex < ez, y with ey <= ex and ey < ez, z otherwise, i.e. (no NaNs)
+             * with ez <= ex and ez <= ey: written so that the three flags are plain mask arithmetic */
             const bool sx = s1 && s2, sy = !s1 && s3;
-            const bool sz = !(sx || sy);
+            const bool sz = !s2 && !s3;
             open = open && !((sx && bx) || (sy && by) || (sz && bz));          /* the bit is set already: the node is left */
             bx = bx || sx; by = by || sy; bz = bz || sz;
             ex = sx ? t1x : ex; ey = sy ? t1y : ey; ez = sz ? t1z : ez;
