@@ -213,7 +213,13 @@ static constexpr int kDoneQuota = PT_DONE_QUOTA;
 /* The render kernel is built twice: for 6 waves per SIMD (80 registers; the octree walk and the
  * triangle test fit, shading spills) and for 4 (128 registers, almost no spills).  Scenes dominated by
  * traversal gain from the extra waves, scenes dominated by entity set-up and shading lose. */
-static constexpr int kWavesHeavy = 6, kWavesLight = 4;
+#ifndef PT_WAVES_HEAVY
+#define PT_WAVES_HEAVY 6
+#endif
+#ifndef PT_WAVES_LIGHT
+#define PT_WAVES_LIGHT 4
+#endif
+static constexpr int kWavesHeavy = PT_WAVES_HEAVY, kWavesLight = PT_WAVES_LIGHT;
 
 /* ------------------------------------------------------------------ closest-hit query kernel */
 template <bool LOG>
