@@ -118,10 +118,13 @@ struct Lane {
  * parameters of the current child (per axis: the node's t1 if the child's bit is set, else tM, the
  * argument table of dgf:178-187): the axis with the smallest exit parameter gets its bit set, or
  * the node is left when that bit is already set.  Bits are only ever set, so the sequence has at
- * most four members and does not depend on which children exist -- it is evaluated once, on entry:
- *   bits  0..11  four 3-bit child numbers (mirrored numbering)
- *   bits 12..15  go:  member i exists in the tree and passes the entry test of dgf:142
- *   bits 16..19  rej: member i exists but fails that test (entered and left at once: it only counts)
+ * most four members and does not depend on which children exist -- it is evaluated once, on entry.
+ * Each step adds a bit to the child number, so the members come in ascending (mirrored) child number and
+ * the list is a set:
+ *   bits  0..7   go:  child c (mirrored numbering) is a member, exists in the tree and passes the entry
+ *                test of dgf:142
+ *   bits  8..15  rej: child c is a member and exists but fails that test (entered and left at once: it
+ *                only counts; kept in counting builds)
  *   bits 24..31  the node's child mask
  * Members after the one that leaves the node have neither flag.
  */
@@ -138,7 +141,7 @@ __device__ __forceinline__ uint32_t child_list(float t0x, float t0y, float t0z, 
     bool bx = !fx && (tMx < te), by = (fx || !fy) && (tMy < te), bz = (fx || fy) && (tMz < te);
     float ex = bx ? t1x : tMx, ey = by ? t1y : tMy, ez = bz ? t1z : tMz;
     uint32_t c = (bx ? 4u : 0u) | (by ? 2u : 0u) | (bz ? 1u : 0u);
-    uint32_t list = (nm << 24) | c;
+    uint32_t list = nm << 24;
     bool open = true;
 #pragma unroll
     for (int i = 0; i < 4; i++) {
@@ -147,8 +150,8 @@ __device__ __forceinline__ uint32_t child_list(float t0x, float t0y, float t0z, 
         /* dgf:142, (ex < 0 || ey < 0 || ey < 0): y twice, never z.  The parameters are products of finite
          * differences and clamped reciprocals, never NaN, so "negative" is "bit pattern above -0.0" */
         const bool rejected = max(__float_as_uint(ex), __float_as_uint(ey)) > 0x80000000u;
-        list |= ((open && !rejected) ? present : 0u) << (12 + i);
-        if (STATS) list |= ((open && rejected) ? present : 0u) << (16 + i);
+        list |= ((open && !rejected) ? present : 0u) << c;
+        if (STATS) list |= ((open && rejected) ? present : 0u) << (c + 8u);
         if (i < 3) {
             const bool s1 = ex < ey, s2 = ex < ez, s3 = ey < ez;              /* next_node, dgf:116-126 */
             /* x wins with ex < ey and ex < ez, y with ey <= ex and ey < ez, z otherwise, i.e. (no NaNs)
@@ -159,7 +162,6 @@ __device__ __forceinline__ uint32_t child_list(float t0x, float t0y, float t0z, 
             bx = bx || sx; by = by || sy; bz = bz || sz;
             ex = sx ? t1x : ex; ey = sy ? t1y : ey; ez = sz ? t1z : ez;
             c |= sx ? 4u : (sy ? 2u : 1u);
-            list |= c << (3 * (i + 1));
         }
     }
     return list;
@@ -271,8 +273,8 @@ __device__ __forceinline__ void entity_block(const PtSceneDev &sc, Lane &L, Stat
  */
 template <bool STATS>
 __device__ __forceinline__ void node_block(const PtSceneDev &sc, Lane &L, Stats &st, float4 *stack, uint32_t *stack1, int stride) {
-    if (((L.todo >> 12) & 0xFu) == 0u) {
-        if (STATS) st.node_visits += __popc((L.todo >> 16) & 0xFu);
+    if ((L.todo & 0xFFu) == 0u) {
+        if (STATS) st.node_visits += __popc((L.todo >> 8) & 0xFFu);
         if (L.level == 0) { L.mode = next_entity_mode(sc, L); return; }     /* walk finished without an accepted leaf */
         L.level--;
         const float4 s = stack[L.level * stride];
@@ -287,14 +289,16 @@ __device__ __forceinline__ void node_block(const PtSceneDev &sc, Lane &L, Stats 
         L.t0x = p0x; L.t1x = p1x; L.t0y = p0y; L.t1y = p1y; L.t0z = p0z; L.t1z = p1z;
         L.nb = __float_as_uint(s.w);
         L.todo = w;
-        if (((w >> 12) & 0xFu) == 0u) return;                /* the parent is exhausted as well: next trip */
+        if ((w & 0xFFu) == 0u) return;                       /* the parent is exhausted as well: next trip */
     }
-    const uint32_t go = (L.todo >> 12) & 0xFu;
-    const int i = __builtin_ctz(go);                          /* go != 0 here */
-    const int curr = (int)((L.todo >> (3 * i)) & 7u);
-    const uint32_t below = (1u << i) - 1u;
-    if (STATS) st.node_visits += 1 + __popc((L.todo >> 16) & below);
-    L.todo &= ~((0x1000u << i) | (below << 16));             /* consumed; passed-over rejects counted */
+    const int curr = __builtin_ctz(L.todo);                   /* lowest go bit = next member (go != 0 here) */
+    if (STATS) {
+        const uint32_t below = (1u << curr) - 1u;
+        st.node_visits += 1 + __popc((L.todo >> 8) & below);
+        L.todo &= ~((1u << curr) | (below << 8));            /* consumed; passed-over rejects counted */
+    } else {
+        L.todo &= L.todo - 1u;                               /* consumed */
+    }
     const uint32_t nm = L.todo >> 24;
     const float tMx = 0.5f * (L.t0x + L.t1x), tMy = 0.5f * (L.t0y + L.t1y), tMz = 0.5f * (L.t0z + L.t1z);
     const int adj = curr ^ L.a;
