@@ -136,7 +136,8 @@ void free_device_side(pt_scene *s) {
     s->bytes_nodes = s->bytes_tris = s->bytes_shade = s->bytes_tex = s->bytes_hdri = 0;
 }
 
-/* appends the triangles ids[0..n) of one run as pairs; returns the index of the run's first pair */
+/* appends the triangles ids[0..n) of one run as pairs; returns where the run starts, in 16-byte units
+ * (the kernels address the pair array by 32-bit byte offsets) */
 uint32_t append_run(std::vector<PtTriPair> &pairs, const float *pos, const int32_t *tri6, const int32_t *ids, int64_t first_id, int64_t n) {
     const uint32_t first = (uint32_t)pairs.size();
     for (int64_t k = 0; k < n; k += 2) {
@@ -156,7 +157,7 @@ uint32_t append_run(std::vector<PtTriPair> &pairs, const float *pos, const int32
         }
         pairs.push_back(pr);
     }
-    return first;
+    return first * (uint32_t)(sizeof(PtTriPair) / 16);
 }
 
 void counters_from(const unsigned long long h[7], pt_counters *c) {
@@ -365,7 +366,7 @@ int pt_scene_commit(pt_scene *scene) {
         }
         ents[i] = e;
     }
-    if (nodes.size() >= (1ull << 32) || recs.size() >= (1ull << 31)) PT_FAIL("pt_scene_commit: scene too large for 32-bit indices");
+    if (nodes.size() >= (1ull << 29) || recs.size() * sizeof(PtTriPair) >= (1ull << 32)) PT_FAIL("pt_scene_commit: scene too large (limits: 4 GiB of triangle pairs, 2^29 octree nodes)");
 
     std::vector<PtMaterial> mats(scene->materials.size());
     for (size_t i = 0; i < scene->materials.size(); i++) {

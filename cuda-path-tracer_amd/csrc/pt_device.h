@@ -73,7 +73,7 @@ struct Best {
     float t, bu, bv;
     int32_t entity;    /* -1 = none */
     int32_t tri;       /* -1 = sphere */
-    uint32_t rec;      /* accepted triangle record: 2 * pair index + slot */
+    uint32_t rec;      /* accepted triangle record: (byte offset of its pair / 16) * 2 + slot */
 };
 
 struct TriLog {        /* optional per-ray record of the triangle-test sequence */
@@ -107,7 +107,7 @@ struct Lane {
     uint32_t path;           /* 3 bits per level: the child slot taken at each ancestor */
     int32_t level, maxd, a;
     /* triangle run (octree leaf or brute-force mesh) */
-    uint32_t tri_cur, tri_left;   /* next triangle pair of the run, triangles still to test */
+    uint32_t tri_cur, tri_left;   /* byte offset of the run's next triangle pair, triangles still to test */
     int32_t run_flags;       /* bit0: some test of this run was accepted, bit1: run is an octree leaf */
 };
 
@@ -225,7 +225,7 @@ __device__ __forceinline__ void entity_block(const PtSceneDev &sc, Lane &L, Stat
     if (!slab_test(e.aabb_min, e.aabb_max, L.o, fr, L.best.t)) return;
     if (e.octree_depth == 0) {            /* dgf:286-291 */
         if (e.n_tris == 0) return;
-        L.tri_cur = e.tri_first; L.tri_left = e.n_tris;
+        L.tri_cur = e.tri_first << 4; L.tri_left = e.n_tris;
         L.run_flags = 0;
         L.mode = M_LEAF;
         return;
@@ -306,7 +306,7 @@ __device__ __forceinline__ void node_block(const PtSceneDev &sc, Lane &L, Stats 
     const PtNode rec = sc.nodes[child];
     if (L.level + 1 == L.maxd) {          /* leaf: dgf:146-157 */
         if (rec.b != 0u) {
-            L.tri_cur = rec.a; L.tri_left = rec.b;
+            L.tri_cur = rec.a << 4; L.tri_left = rec.b;
             L.run_flags = 2;
             L.mode = M_LEAF;
         }
@@ -355,9 +355,10 @@ template <bool STATS, bool LOG>
 __device__ __forceinline__ void leaf_block(const PtSceneDev &sc, Lane &L, Stats &st, TriLog &lg) {
     const uint32_t idx = L.tri_cur;
     const bool two = L.tri_left != 1u;
-    const float4 *q = reinterpret_cast<const float4 *>(sc.tris + idx);
+    /* uniform base + 32-bit lane offset: the loads need no 64-bit address arithmetic */
+    const float4 *q = reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(sc.tris) + idx);
     const float4 r0 = q[0], r1 = q[1], r2 = q[2], r3 = q[3], r4 = q[4];
-    L.tri_cur = idx + 1u;
+    L.tri_cur = idx + (uint32_t)sizeof(PtTriPair);
     L.tri_left -= two ? 2u : 1u;
     if (STATS) st.tri_tests += two ? 2u : 1u;
     const int32_t id_a = __float_as_int(r4.z), id_b = __float_as_int(r4.w);
@@ -414,7 +415,7 @@ __device__ __forceinline__ void leaf_block(const PtSceneDev &sc, Lane &L, Stats 
         bt = acc ? t : bt; bbu = acc ? u : bbu; bbv = acc ? v : bbv;
         bent = acc ? L.ent - 1 : bent;
         btri = acc ? (second ? id_b : id_a) : btri;
-        brec = acc ? (2u * idx + (second ? 1u : 0u)) : brec;
+        brec = acc ? ((idx >> 3) | (second ? 1u : 0u)) : brec;
         flags = acc ? (flags | 1) : flags;
     }
     L.best.t = bt; L.best.bu = bbu; L.best.bv = bbv; L.best.tri = btri; L.best.entity = bent; L.best.rec = brec;
@@ -477,7 +478,7 @@ __device__ __forceinline__ void finish_hit(const PtSceneDev &sc, V3 o, V3 d, con
         sf.normal = normalized(sf.position - mk(e.center[0], e.center[1], e.center[2]));
         return;
     }
-    const float *pf = sc.tris[best.rec >> 1].f + (best.rec & 1u);
+    const float *pf = reinterpret_cast<const float *>(reinterpret_cast<const char *>(sc.tris) + (size_t)(best.rec >> 1) * 16u) + (best.rec & 1u);
     const V3 e1 = mk(pf[6], pf[8], pf[10]), e2 = mk(pf[12], pf[14], pf[16]);
     sf.normal = normalized(cross3(e1, e2));
     if (e.has_uvs || e.smooth_shading) {

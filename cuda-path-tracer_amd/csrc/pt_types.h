@@ -22,7 +22,7 @@
 #define PT_SHAPE_MESH 1
 
 struct PtNode {
-    uint32_t a;   /* inner: index of first child;   leaf: index of first triangle pair */
+    uint32_t a;   /* inner: index of first child;   leaf: first triangle pair, in 16-byte units */
     uint32_t b;   /* inner: 8-bit child mask;       leaf: number of triangles */
 };
 
@@ -48,7 +48,7 @@ struct alignas(16) PtEntity {
     int32_t  octree_depth;     /* 0 = brute force */
     uint32_t root_node;        /* index into nodes[] */
     float    aabb_min[3];
-    uint32_t tri_first;        /* brute force: first triangle pair */
+    uint32_t tri_first;        /* brute force: first triangle pair, in 16-byte units */
     float    aabb_max[3];
     uint32_t n_tris;           /* brute force: number of triangles */
     float    region_min[3];    /* octree root region (the entity AABB when the octree was built) */
