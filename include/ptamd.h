@@ -115,7 +115,10 @@ int pt_scene_add_sphere(pt_scene *scene, const float center[3], float radius, in
 /* rgb: h x w x 3 floats, row 0 first (src/scene.cu:19-55) */
 int pt_scene_set_hdri(pt_scene *scene, const float *rgb, int w, int h, float exposure,
                       float contrast, float rot_offset, int smooth);
-/* flattens every octree into the linear node / triangle-record arrays and uploads the scene */
+/* flattens every octree into the linear node / triangle-pair arrays and uploads the scene.  Also picks
+ * which build of the render kernel later calls use (many waves and few registers for scenes dominated
+ * by octree traversal, fewer waves otherwise); the environment variable PTAMD_KERNEL = heavy | light
+ * overrides the choice.  Limits: 2^29 octree nodes and 4 GiB of triangle pairs per scene. */
 int pt_scene_commit(pt_scene *scene);
 int pt_scene_octree_info(pt_scene *scene, int entity, pt_octree_info *info);
 /* canonical pre-order dump of the flattened octree: per node {depth, slot, child mask, n_tris,
