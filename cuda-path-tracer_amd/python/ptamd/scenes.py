@@ -189,7 +189,10 @@ def tube_mesh(nu, nv, curve, radius_fn, seed, displacement):
     b = idx[1:, :-1].ravel()
     c = idx[1:, 1:].ravel()
     d = idx[:-1, 1:].ravel()
-    faces = np.concatenate([np.stack([a, b, c], axis=1), np.stack([a, c, d], axis=1)], axis=0).astype(np.int32)
+    # counter-clockwise seen from outside: cross(v1 - v0, v2 - v0) points away from the curve.  The
+    # renderer never flips normals (src/device_geometry_functions.cuh:319-365), so an inward
+    # winding would send every bounce into the tube.
+    faces = np.concatenate([np.stack([a, c, b], axis=1), np.stack([a, d, c], axis=1)], axis=0).astype(np.int32)
     return pos, faces, uv
 
 
