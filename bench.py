@@ -105,6 +105,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    launch = scene.launch()      # the render kernel's launch choices (kernel build, quorum) picked at commit
     for _ in range(args.warmup):
         step()
     # one untimed pass with the in-kernel work counters (identical work: same seed, same samples)
@@ -178,7 +179,7 @@ def main():
             tc = time.perf_counter()
             osc.render(ocam, 1337, 0, 1, rows=rows, n_threads=cores)
             t1 = time.perf_counter() - tc
-            n_cpu = int(max(1, min(64, round(15.0 / max(t1, 1e-3)))))
+            n_cpu = int(max(1, min(256, round(15.0 / max(t1, 1e-3)))))
             tc = time.perf_counter()
             _, ccnt = osc.render(ocam, 1337, 1, 1 + n_cpu, rows=rows, n_threads=cores)
             tn = time.perf_counter() - tc
@@ -196,7 +197,7 @@ def main():
                        "spp": spp, "samples_per_rank": s_end - s_begin, "parallelism": f"sample-shard x{world}"},
             "time_to_spp_s": round(ms_per_step / 1000.0, 4),
             "msegments_per_s": round(total_counters["segments"] / (ms_per_step / 1000.0) / 1e6, 2),
-            "counters": total_counters, "schedule": schedule,
+            "counters": total_counters, "schedule": schedule, "launch": launch,
             "roofline": roofline, "cpu_baseline": cpu_baseline,
             "post_chain_ms": None if post_ms is None else round(post_ms, 2),
             "scene_gen_s": round(t_gen, 2), "scene_build_upload_s": round(t_upload, 2),

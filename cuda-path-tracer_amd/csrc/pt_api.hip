@@ -65,7 +65,10 @@ struct pt_scene {
     bool has_hdri = false, hdri_smooth = false;
 
     bool committed = false;
+    /* launch choices of the render kernel (defaults picked at commit, pt_scene_set_launch overrides) */
     bool heavy = false;        /* traversal-dominated scene: render with the many-waves build of the kernel */
+    int quorum = 12;           /* finished lanes per wave that make it leave the geometry blocks to shade / refill */
+    bool build_fixed = false, quorum_fixed = false;   /* set by the caller or the environment: commit keeps them */
     PtSceneDev dev{};
     std::vector<void *> allocs;
     uint64_t bytes_nodes = 0, bytes_tris = 0, bytes_shade = 0, bytes_tex = 0, bytes_hdri = 0;
@@ -411,13 +414,28 @@ int pt_scene_commit(pt_scene *scene) {
     /* which build of the render kernel: scenes with a large octree spend their time in the walk and
      * the triangle tests (measured cross-over between 24 k and 128 k triangle pairs); PTAMD_KERNEL =
      * heavy | light overrides */
-    scene->heavy = max_depth > 0 && recs.size() >= 65536;
+    if (!scene->build_fixed) scene->heavy = max_depth > 0 && recs.size() >= 65536;
     if (const char *k = getenv("PTAMD_KERNEL")) {
-        if (!strcmp(k, "heavy")) scene->heavy = true;
-        else if (!strcmp(k, "light")) scene->heavy = false;
+        if (!strcmp(k, "heavy")) { scene->heavy = true; scene->build_fixed = true; }
+        else if (!strcmp(k, "light")) { scene->heavy = false; scene->build_fixed = true; }
+    }
+    /* the quorum: a refill round (shading, new paths, their entity set-up) costs the same whatever the
+     * number of lanes it serves, so it should serve many where it is expensive next to the walk that
+     * separates two rounds -- textured materials (measured optimum 40 of 64 lanes against 12: +5 %) and
+     * most of all scenes without any octree, where there is no walk at all (62: +34 %) -- and few
+     * inside deep trees, where lanes waiting for a refill idle through many walk steps */
+    if (!scene->quorum_fixed) {
+        bool textured = false;
+        for (const MaterialHost &m : scene->materials)
+            for (int k = 0; k < 4; k++) textured = textured || !m.maps[k].empty();
+        scene->quorum = max_depth == 0 ? 62 : (textured ? 40 : 12);
+    }
+    if (const char *k = getenv("PTAMD_QUORUM")) {
+        const int q = atoi(k);
+        if (q >= 1 && q <= 64) { scene->quorum = q; scene->quorum_fixed = true; }
     }
 
-    PT_HIP(hipMalloc((void **)&scene->d_tickets, kMaxQueues * sizeof(uint32_t)));
+    PT_HIP(hipMalloc((void **)&scene->d_tickets, (kMaxQueues + 1) * sizeof(uint32_t)));
     PT_HIP(hipMalloc((void **)&scene->d_stats, 16 * sizeof(unsigned long long)));
     scene->committed = true;
     return 0;
@@ -537,21 +555,12 @@ int pt_camera_rays(int device, const pt_camera *camera, uint32_t seed, int sampl
     return rc;
 }
 
-int pt_render_accumulate(pt_scene *scene, const pt_camera *camera, uint32_t seed, int sample_begin, int sample_end,
-                         int n_split, float *d_split, pt_counters *counters, void *stream_) {
-    if (!scene || !camera || !d_split) PT_FAIL("pt_render_accumulate: null argument");
-    if (!scene->committed) PT_FAIL("pt_render_accumulate: scene not committed");
-    if (camera->res_x <= 0 || camera->res_y <= 0) PT_FAIL("pt_render_accumulate: empty image");
-    if (sample_begin < 0 || sample_end < sample_begin) PT_FAIL("pt_render_accumulate: bad sample range");
-    if (n_split < 1 || n_split > 64) PT_FAIL("pt_render_accumulate: n_split must be in [1,64]");
-    if (!is_device_pointer(d_split)) PT_FAIL("pt_render_accumulate: d_split must be a device pointer");
-    if (sample_end == sample_begin) {
-        if (counters) memset(counters, 0, sizeof *counters);
-        return 0;
-    }
-    DeviceGuard g(scene->device);
-    hipStream_t stream = (hipStream_t)stream_;
-    RenderParams p;
+namespace {
+
+/* fills everything of the launch parameters that follows from the camera and the sample range, and
+ * makes the workspace large enough */
+int prepare_render(pt_scene *scene, const pt_camera *camera, uint32_t seed, int sample_begin, int sample_end, int n_split,
+                   hipStream_t stream, RenderParams &p) {
     memset(&p, 0, sizeof p);
     p.sc = scene->dev;
     p.cam = *camera;
@@ -577,14 +586,43 @@ int pt_render_accumulate(pt_scene *scene, const pt_camera *camera, uint32_t seed
     }
     p.partials = (float *)scene->partials.p;
     p.tickets = scene->d_tickets;
+    p.stats = nullptr;
+    p.done_quota = scene->quorum;
+    return 0;
+}
+
+int ensure_events(pt_scene *scene) {
+    if (!scene->ev_start) {
+        PT_HIP(hipEventCreate(&scene->ev_start));
+        PT_HIP(hipEventCreate(&scene->ev_stop));
+    }
+    return 0;
+}
+
+}  // namespace
+
+int pt_render_accumulate(pt_scene *scene, const pt_camera *camera, uint32_t seed, int sample_begin, int sample_end,
+                         int n_split, float *d_split, pt_counters *counters, void *stream_) {
+    if (!scene || !camera || !d_split) PT_FAIL("pt_render_accumulate: null argument");
+    if (!scene->committed) PT_FAIL("pt_render_accumulate: scene not committed");
+    if (camera->res_x <= 0 || camera->res_y <= 0) PT_FAIL("pt_render_accumulate: empty image");
+    if (sample_begin < 0 || sample_end < sample_begin) PT_FAIL("pt_render_accumulate: bad sample range");
+    if (n_split < 1 || n_split > 64) PT_FAIL("pt_render_accumulate: n_split must be in [1,64]");
+    if (!is_device_pointer(d_split)) PT_FAIL("pt_render_accumulate: d_split must be a device pointer");
+    if (sample_end == sample_begin) {
+        if (counters) memset(counters, 0, sizeof *counters);
+        return 0;
+    }
+    DeviceGuard g(scene->device);
+    hipStream_t stream = (hipStream_t)stream_;
+    const int64_t n_pixels = (int64_t)camera->res_x * camera->res_y;
+    RenderParams p;
+    if (prepare_render(scene, camera, seed, sample_begin, sample_end, n_split, stream, p)) return 1;
     p.stats = counters ? scene->d_stats : nullptr;
-    PT_HIP(hipMemsetAsync(scene->d_tickets, 0, kMaxQueues * sizeof(uint32_t), stream));
+    PT_HIP(hipMemsetAsync(scene->d_tickets, 0, (kMaxQueues + 1) * sizeof(uint32_t), stream));
     if (counters) PT_HIP(hipMemsetAsync(scene->d_stats, 0, 16 * sizeof(unsigned long long), stream));
     if (scene->profiling) {
-        if (!scene->ev_start) {
-            PT_HIP(hipEventCreate(&scene->ev_start));
-            PT_HIP(hipEventCreate(&scene->ev_stop));
-        }
+        if (ensure_events(scene)) return 1;
         PT_HIP(hipEventRecord(scene->ev_start, stream));
     }
     if (launch_render(p, scene->n_cu, kMaxQueues, scene->heavy, stream)) return 1;
@@ -599,6 +637,22 @@ int pt_render_accumulate(pt_scene *scene, const pt_camera *camera, uint32_t seed
         PT_HIP(hipStreamSynchronize(stream));
         counters_from(h, counters);
     }
+    return 0;
+}
+
+int pt_scene_set_launch(pt_scene *scene, int kernel_build, int quorum) {
+    if (!scene) PT_FAIL("pt_scene_set_launch: null argument");
+    if (kernel_build < -1 || kernel_build > 1) PT_FAIL("pt_scene_set_launch: kernel_build must be -1 (keep), 0 (light) or 1 (heavy)");
+    if (quorum < 0 || quorum > 64) PT_FAIL("pt_scene_set_launch: quorum must be 0 (keep) or in [1,64]");
+    if (kernel_build >= 0) { scene->heavy = kernel_build == 1; scene->build_fixed = true; }
+    if (quorum > 0) { scene->quorum = quorum; scene->quorum_fixed = true; }
+    return 0;
+}
+
+int pt_scene_get_launch(pt_scene *scene, int *kernel_build, int *quorum) {
+    if (!scene) PT_FAIL("pt_scene_get_launch: null argument");
+    if (kernel_build) *kernel_build = scene->heavy ? 1 : 0;
+    if (quorum) *quorum = scene->quorum;
     return 0;
 }
 

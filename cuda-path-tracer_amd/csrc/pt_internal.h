@@ -45,9 +45,10 @@ struct RenderParams {
     int mtiles_x, mtiles_y;      /* 8x8-tile macro tiles covering the tiles */
     uint32_t n_items;            /* mtiles_x * mtiles_y * 64 tiles * slices */
     uint32_t n_queues;           /* == gridDim.x: every workgroup owns one contiguous range of the items */
-    uint32_t *tickets;           /* n_queues cursors, zeroed before the launch */
+    uint32_t *tickets;           /* n_queues cursors, then the number of exhausted queues; zeroed before the launch */
     float *partials;             /* [n_split * slices_per_split][H*W][3] */
     unsigned long long *stats;   /* 7 counters, or null */
+    int done_quota;              /* finished lanes per wave at which it leaves the geometry blocks to shade / refill */
 };
 
 /* kernel launchers (pt_kernels.hip); all asynchronous on `stream` */

@@ -393,7 +393,12 @@ __global__ void __launch_bounds__(kBlock, WAVES) render_kernel(RenderParams P) {
                             const uint32_t hi = (uint32_t)(((unsigned long long)P.n_items * (q + 1u)) / nq);
                             const uint32_t t = atomicAdd(&P.tickets[q], 1u);
                             if (t < hi - lo) { id = lo + t; break; }
-                            q = (q + 1u == nq) ? 0u : q + 1u;        /* this range is finished for good: move on */
+                            /* this range is finished for good; the first draw past its end reports it, and once
+                             * every range is reported nothing is left anywhere (without this each wave would
+                             * probe all the ranges before it retires: milliseconds at the end of a launch) */
+                            if (t == hi - lo) atomicAdd(&P.tickets[nq], 1u);
+                            if (__hip_atomic_load(&P.tickets[nq], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= nq) break;
+                            q = (q + 1u == nq) ? 0u : q + 1u;
                             if (++probes >= nq) break;               /* every range has been seen empty */
                         }
                     }
@@ -448,7 +453,7 @@ __global__ void __launch_bounds__(kBlock, WAVES) render_kernel(RenderParams P) {
             if (__ballot(!done) == 0ull) break;      /* every lane is out of work: the grid drains */
             continue;                                /* e.g. lanes that drew an out-of-image slot ask again */
         }
-        trace_wave<STATS, false>(P.sc, L, st, lg, stack, stack1, kBlock, kDoneQuota);
+        trace_wave<STATS, false>(P.sc, L, st, lg, stack, stack1, kBlock, P.done_quota);
     }
     if (STATS && P.stats) {
         flush_stat(&P.stats[0], st.segments);

@@ -115,10 +115,12 @@ int pt_scene_add_sphere(pt_scene *scene, const float center[3], float radius, in
 /* rgb: h x w x 3 floats, row 0 first (src/scene.cu:19-55) */
 int pt_scene_set_hdri(pt_scene *scene, const float *rgb, int w, int h, float exposure,
                       float contrast, float rot_offset, int smooth);
-/* flattens every octree into the linear node / triangle-pair arrays and uploads the scene.  Also picks
- * which build of the render kernel later calls use (many waves and few registers for scenes dominated
- * by octree traversal, fewer waves otherwise); the environment variable PTAMD_KERNEL = heavy | light
- * overrides the choice.  Limits: 2^29 octree nodes and 4 GiB of triangle pairs per scene. */
+/* flattens every octree into the linear node / triangle-pair arrays and uploads the scene.  Also sets
+ * the defaults of the two launch choices of the render kernel (see pt_scene_set_launch): the build --
+ * many waves and few registers for scenes with a large octree, fewer waves otherwise -- and the
+ * quorum (62 without any octree, 40 with textured materials, else 12); the environment variables
+ * PTAMD_KERNEL = heavy | light and PTAMD_QUORUM = 1..64 fix them.  Limits: 2^29 octree nodes and
+ * 4 GiB of triangle pairs per scene. */
 int pt_scene_commit(pt_scene *scene);
 int pt_scene_octree_info(pt_scene *scene, int entity, pt_octree_info *info);
 /* canonical pre-order dump of the flattened octree: per node {depth, slot, child mask, n_tris,
@@ -149,6 +151,16 @@ int pt_camera_rays(int device, const pt_camera *camera, uint32_t seed, int sampl
 int pt_render_accumulate(pt_scene *scene, const pt_camera *camera, uint32_t seed,
                          int sample_begin, int sample_end, int n_split, float *d_split,
                          pt_counters *counters, void *stream);
+/* Launch choices (no counterpart in the reference).  The render kernel has two launch choices that
+ * change how a wave schedules its lanes and nothing a path computes (images are bit-identical under
+ * all of them): the kernel build (0 = light: 4 waves per SIMD, 1 = heavy: 6 waves, fewer registers)
+ * and the quorum (how many of a wave's 64 lanes must have finished their ray before the wave leaves
+ * the geometry blocks to shade and refill them: high where shading dominates, low inside deep
+ * trees).  pt_scene_commit picks defaults from the scene; pt_scene_set_launch fixes a choice for
+ * this and later commits (kernel_build -1 / quorum 0 = leave as is); pt_scene_get_launch reports
+ * the current ones (outputs may be NULL). */
+int pt_scene_set_launch(pt_scene *scene, int kernel_build, int quorum);
+int pt_scene_get_launch(pt_scene *scene, int *kernel_build, int *quorum);
 /* Measurement aid (no counterpart in the reference): when enabled, every pt_render_accumulate
  * brackets its path-tracing kernel with two HIP events on the launch stream;
  * pt_scene_last_render_kernel_ms waits for the last launch and returns its duration. */
