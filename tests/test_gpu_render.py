@@ -124,6 +124,30 @@ def test_both_kernel_builds_give_identical_images(pt, scenes, monkeypatch):
     assert out["light"][0].max() > 0
 
 
+def test_launch_choices_do_not_change_the_image(pt, scenes):
+    """Kernel build and quorum only change how a wave schedules its lanes: every combination gives
+    the bits of the default launch, work counters included; commit derives the defaults from the scene."""
+    desc = scenes.hcandersen_scene(res=(96, 54), n_tris=6000, tex_res=128, hdri_res=(128, 64))
+    g, cam = pt.scene_from_description(desc)
+    assert g.launch() == dict(kernel_build="light", quorum=40)        # small textured mesh with an octree
+    ref_img, ref_cnt = pt.render_image(g, cam, 24, seed=5, want_counters=True)
+    for build, quorum in (("heavy", 1), ("heavy", 62), ("light", 12), ("light", 64), ("heavy", 33)):
+        g.set_launch(build, quorum)
+        assert g.launch() == dict(kernel_build=build, quorum=quorum)
+        img, cnt = pt.render_image(g, cam, 24, seed=5, want_counters=True)
+        assert np.array_equal(img.view(np.uint32), ref_img.view(np.uint32)), (build, quorum)
+        assert cnt == ref_cnt, (build, quorum)
+    with pytest.raises(pt.PtError, match="quorum"):
+        g.set_launch(None, 65)
+    g.close()
+    c, _ = pt.scene_from_description(scenes.cornellbox_scene(res=(40, 24)))
+    assert c.launch() == dict(kernel_build="light", quorum=62)        # no octree anywhere
+    c.close()
+    t, _ = pt.scene_from_description(scenes.teapot_scene(res=(64, 36)))
+    assert t.launch() == dict(kernel_build="light", quorum=12)        # untextured octree mesh
+    t.close()
+
+
 def test_render_edge_cases(pt, scenes):
     desc = scenes.cornellbox_scene(res=(40, 24))
     g, cam = pt.scene_from_description(desc)
