@@ -190,7 +190,8 @@ int pt_device_name(int device, char *buf, size_t cap) {
     if (!buf || cap == 0) PT_FAIL("pt_device_name: null buffer");
     hipDeviceProp_t prop;
     PT_HIP(hipGetDeviceProperties(&prop, device));
-    snprintf(buf, cap, "%s", prop.name);
+    /* some driver stacks leave the marketing name empty: fall back to the architecture name */
+    snprintf(buf, cap, "%s", prop.name[0] ? prop.name : prop.gcnArchName);
     return 0;
 }
 
