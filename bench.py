@@ -161,6 +161,7 @@ def main():
     if rank == 0:
         # post-processing (reported separately): the reference's fixed chain, device resident
         out = torch.empty_like(local_sum)
+        ptamd.check(L.pt_post_chain(dev, local_sum.data_ptr(), out.data_ptr(), res[0], res[1], spp, stream))   # loads the kernels
         torch.cuda.synchronize()
         tp = time.perf_counter()
         ptamd.check(L.pt_post_chain(dev, local_sum.data_ptr(), out.data_ptr(), res[0], res[1], spp, stream))

@@ -10,8 +10,15 @@
  * "crop" rule (taps outside the image contribute neither colour nor weight) holds at the borders.
  * Tap weights are wave-uniform and are read through the scalar path.  No MFMA: a stencil with a
  * per-pixel normalisation (and, for BILATERAL, a data-dependent weight) is not a dense contraction.
+ *
+ * NORMAL filters whose tap table is an outer product a[y] * b[x] (the gaussian and mean tables of
+ * src/post_processing.cu:51-84 are) run as two one-dimensional passes instead: the window cropped
+ * to the image is a rectangle, so both the weighted sum and the weight total factor exactly, and
+ * the 65x65 bloom costs 130 multiply-adds per pixel and channel instead of 4225.  Only the order of
+ * the floating-point additions differs from the two-dimensional loop.
  */
 #include <cmath>
+#include <cstring>
 #include <vector>
 
 #include "pt_internal.h"
@@ -75,6 +82,76 @@ __global__ void __launch_bounds__(kPostBlock) filter_kernel(const float *__restr
             wsum += wgt;
         }
     }
+    float *o = out + 3 * ((size_t)v * w + u);
+    o[0] = pr / wsum; o[1] = pg / wsum; o[2] = pb / wsum;
+}
+
+/* separable NORMAL filter, pass along x: out(x, y) = sum over in-image dx of b[dx] * in(x + dx, y), not normalised.
+ * One workgroup = 256 consecutive pixels of one row, staged with their halo as three planes. */
+__global__ void __launch_bounds__(kPostBlock) sep_row_kernel(const float *__restrict__ in, float *__restrict__ out, int w, int h,
+                                                             const float *__restrict__ b, int ks) {
+    extern __shared__ float lds[];
+    const int tw = kPostBlock + 2 * ks;
+    float *R = lds, *G = lds + tw, *B = lds + 2 * tw;
+    const int y = blockIdx.y, x0 = blockIdx.x * kPostBlock - ks;
+    for (int i = threadIdx.x; i < tw; i += kPostBlock) {
+        const int gx = x0 + i;
+        float r = 0.f, g = 0.f, bl = 0.f;
+        if (gx >= 0 && gx < w) {
+            const float *p = in + 3 * ((size_t)y * w + gx);
+            r = p[0]; g = p[1]; bl = p[2];
+        }
+        R[i] = r; G[i] = g; B[i] = bl;
+    }
+    __syncthreads();
+    const int u = blockIdx.x * kPostBlock + threadIdx.x;
+    if (u >= w) return;
+    const int c = threadIdx.x + ks;
+    float pr = 0.f, pg = 0.f, pb = 0.f;
+    for (int dx = -ks; dx <= ks; dx++) {          /* out-of-image texels are staged as zeros */
+        const float t = b[ks + dx];
+        pr = pr + t * R[c + dx];
+        pg = pg + t * G[c + dx];
+        pb = pb + t * B[c + dx];
+    }
+    float *o = out + 3 * ((size_t)y * w + u);
+    o[0] = pr; o[1] = pg; o[2] = pb;
+}
+
+/* pass along y over the row sums, and the normalisation by the weight of the cropped window:
+ * (sum of a over in-image rows) * (sum of b over in-image columns) */
+__global__ void __launch_bounds__(kPostBlock) sep_col_kernel(const float *__restrict__ in, float *__restrict__ out, int w, int h,
+                                                             const float *__restrict__ a, const float *__restrict__ b, int ks) {
+    extern __shared__ float lds[];
+    const int th = kTileH + 2 * ks;
+    const int plane = kTileW * th;
+    float *R = lds, *G = lds + plane, *B = lds + 2 * plane;
+    const int x0 = blockIdx.x * kTileW, y0 = blockIdx.y * kTileH - ks;
+    for (int i = threadIdx.x; i < plane; i += kPostBlock) {
+        const int ly = i / kTileW, lx = i - ly * kTileW;
+        const int gx = x0 + lx, gy = y0 + ly;
+        float r = 0.f, g = 0.f, bl = 0.f;
+        if (gx < w && gy >= 0 && gy < h) {
+            const float *p = in + 3 * ((size_t)gy * w + gx);
+            r = p[0]; g = p[1]; bl = p[2];
+        }
+        R[i] = r; G[i] = g; B[i] = bl;
+    }
+    __syncthreads();
+    const int lx = threadIdx.x % kTileW, ly = threadIdx.x / kTileW;
+    const int u = x0 + lx, v = blockIdx.y * kTileH + ly;
+    if (u >= w || v >= h) return;
+    const int c = (ly + ks) * kTileW + lx;
+    float pr = 0.f, pg = 0.f, pb = 0.f, wy = 0.f, wx = 0.f;
+    for (int d = -ks; d <= ks; d++) {
+        const float ta = a[ks + d], tb = b[ks + d];
+        pr = pr + ta * R[c + d * kTileW];
+        pg = pg + ta * G[c + d * kTileW];
+        pb = pb + ta * B[c + d * kTileW];
+        wy += (v + d >= 0 && v + d < h) ? ta : 0.f;
+        wx += (u + d >= 0 && u + d < w) ? tb : 0.f;
+    }
+    const float wsum = wy * wx;
     float *o = out + 3 * ((size_t)v * w + u);
     o[0] = pr / wsum; o[1] = pg / wsum; o[2] = pb / wsum;
 }
@@ -143,6 +220,38 @@ static int run_filter(const float *d_in, float *d_out, int w, int h, const float
     return 0;
 }
 
+/* a[y] * b[x] == taps[y][x] for every tap (to a few ulp)?  Then a and b (2*ks+1 floats each) are filled in. */
+static bool factor_taps(const float *taps, int ks, std::vector<float> &a, std::vector<float> &b) {
+    const int kw = 2 * ks + 1;
+    const float c = taps[(size_t)ks * kw + ks];
+    if (!(std::fabs(c) > 0.0f) || !std::isfinite(c)) return false;
+    a.resize(kw); b.resize(kw);
+    for (int i = 0; i < kw; i++) {
+        a[i] = taps[(size_t)i * kw + ks];
+        b[i] = taps[(size_t)ks * kw + i] / c;
+    }
+    for (int y = 0; y < kw; y++)
+        for (int x = 0; x < kw; x++) {
+            const float t = taps[(size_t)y * kw + x], p = a[y] * b[x];
+            if (!std::isfinite(t) || std::fabs(t - p) > 2e-6f * std::fabs(t) + 1e-37f) return false;
+        }
+    return true;
+}
+
+/* the two passes; d_ab = a then b on the device, d_tmp = one image of scratch (may not alias in or out) */
+static int run_separable(const float *d_in, float *d_tmp, float *d_out, int w, int h, const float *d_ab, int ks, hipStream_t stream) {
+    const int kw = 2 * ks + 1;
+    const size_t lds_row = (size_t)3 * (kPostBlock + 2 * ks) * sizeof(float);
+    const size_t lds_col = (size_t)3 * kTileW * (kTileH + 2 * ks) * sizeof(float);
+    if (lds_row > 64 * 1024 || lds_col > 64 * 1024) PT_FAIL("pt_apply_filter: kernel size too large for the LDS tile");
+    hipLaunchKernelGGL(sep_row_kernel, dim3((w + kPostBlock - 1) / kPostBlock, h), dim3(kPostBlock), lds_row, stream, d_in, d_tmp, w, h,
+                       d_ab + kw, ks);
+    hipLaunchKernelGGL(sep_col_kernel, dim3((w + kTileW - 1) / kTileW, (h + kTileH - 1) / kTileH), dim3(kPostBlock), lds_col, stream,
+                       (const float *)d_tmp, d_out, w, h, d_ab, d_ab + kw, ks);
+    PT_HIP(hipGetLastError());
+    return 0;
+}
+
 struct DevSel {
     int prev = -1;
     explicit DevSel(int dev) {
@@ -190,14 +299,28 @@ int pt_apply_filter(int device, const float *d_in, float *d_out, int w, int h, c
     DevSel g(device);
     hipStream_t stream = (hipStream_t)stream_;
     const size_t nt = (size_t)(2 * ksize + 1) * (2 * ksize + 1);
-    float *d_taps = nullptr;
-    PT_HIP(hipMalloc((void **)&d_taps, nt * sizeof(float)));
+    std::vector<float> fa, fb;
+    const size_t lds_col = (size_t)3 * kTileW * (kTileH + 2 * ksize) * sizeof(float);
+    const bool separable = filter_type == 0 && lds_col <= 64 * 1024 && (size_t)h < 65536 && factor_taps(taps, ksize, fa, fb);
+    float *d_taps = nullptr, *d_tmp = nullptr;
+    PT_HIP(hipMalloc((void **)&d_taps, (nt < 2 ? 2 : nt) * sizeof(float)));     /* a 1 x 1 table still factors into two */
     int rc = 0;
-    if (hipMemcpyAsync(d_taps, taps, nt * sizeof(float), hipMemcpyHostToDevice, stream) != hipSuccess) { rc = 1; set_error("pt_apply_filter: tap upload failed"); }
-    if (!rc) rc = run_filter(d_in, d_out, w, h, d_taps, ksize, filter_type, stream);
-    /* the taps buffer must outlive the kernel */
+    if (separable) {
+        const size_t kw = 2 * (size_t)ksize + 1;
+        if (hipMalloc((void **)&d_tmp, (size_t)w * h * 12) != hipSuccess) { rc = 1; set_error("pt_apply_filter: out of device memory"); }
+        if (!rc && (hipMemcpyAsync(d_taps, fa.data(), kw * sizeof(float), hipMemcpyHostToDevice, stream) != hipSuccess ||
+                    hipMemcpyAsync(d_taps + kw, fb.data(), kw * sizeof(float), hipMemcpyHostToDevice, stream) != hipSuccess)) {
+            rc = 1; set_error("pt_apply_filter: tap upload failed");
+        }
+        if (!rc) rc = run_separable(d_in, d_tmp, d_out, w, h, d_taps, ksize, stream);
+    } else {
+        if (hipMemcpyAsync(d_taps, taps, nt * sizeof(float), hipMemcpyHostToDevice, stream) != hipSuccess) { rc = 1; set_error("pt_apply_filter: tap upload failed"); }
+        if (!rc) rc = run_filter(d_in, d_out, w, h, d_taps, ksize, filter_type, stream);
+    }
+    /* the taps (host vectors included) and the scratch image must outlive the kernels */
     if (hipStreamSynchronize(stream) != hipSuccess && !rc) { rc = 1; set_error("pt_apply_filter: kernel failed"); }
     (void)hipFree(d_taps);
+    if (d_tmp) (void)hipFree(d_tmp);
     return rc;
 }
 
@@ -254,6 +377,8 @@ int pt_post_chain(int device, const float *d_sum, float *d_out, int w, int h, un
     std::vector<float> bloom_taps(65 * 65), bil_taps(5 * 5);
     pt_make_gaussian(32, 10.0f, bloom_taps.data());
     pt_make_gaussian(2, 0.7f, bil_taps.data());
+    std::vector<float> fa, fb;
+    const bool separable = h < 65536 && factor_taps(bloom_taps.data(), 32, fa, fb);
     float *d_img = nullptr, *d_bright = nullptr, *d_bloom = nullptr, *d_taps = nullptr;
     int rc = 0;
     do {
@@ -261,13 +386,22 @@ int pt_post_chain(int device, const float *d_sum, float *d_out, int w, int h, un
             hipMalloc((void **)&d_bloom, img_bytes) != hipSuccess || hipMalloc((void **)&d_taps, (65 * 65 + 25) * sizeof(float)) != hipSuccess) {
             rc = 1; set_error("pt_post_chain: out of device memory"); break;
         }
+        if (separable) {     /* a, b at the head of the 65 x 65 slot */
+            memcpy(bloom_taps.data(), fa.data(), 65 * sizeof(float));
+            memcpy(bloom_taps.data() + 65, fb.data(), 65 * sizeof(float));
+        }
         if (hipMemcpyAsync(d_taps, bloom_taps.data(), 65 * 65 * 4, hipMemcpyHostToDevice, stream) != hipSuccess ||
             hipMemcpyAsync(d_taps + 65 * 65, bil_taps.data(), 25 * 4, hipMemcpyHostToDevice, stream) != hipSuccess) {
             rc = 1; set_error("pt_post_chain: tap upload failed"); break;
         }
         hipLaunchKernelGGL(chain_pre_kernel, dim3(grid1(n_pixels)), dim3(kPostBlock), 0, stream, d_sum, d_img, d_bright, n_pixels, (float)n_samples, 3.0f);
-        if ((rc = run_filter(d_bright, d_bloom, w, h, d_taps, 32, 0, stream))) break;
-        hipLaunchKernelGGL(chain_mid_kernel, dim3(grid1(3 * n_pixels)), dim3(kPostBlock), 0, stream, d_img, d_bloom, 3 * n_pixels, 0.5f, 1.0f / 2.2f);
+        const float *d_glow = d_bloom;
+        if (separable) {
+            /* row sums into d_bloom, column pass back into d_bright (the thresholded image is no longer needed) */
+            if ((rc = run_separable(d_bright, d_bloom, d_bright, w, h, d_taps, 32, stream))) break;
+            d_glow = d_bright;
+        } else if ((rc = run_filter(d_bright, d_bloom, w, h, d_taps, 32, 0, stream))) break;
+        hipLaunchKernelGGL(chain_mid_kernel, dim3(grid1(3 * n_pixels)), dim3(kPostBlock), 0, stream, d_img, d_glow, 3 * n_pixels, 0.5f, 1.0f / 2.2f);
         if ((rc = run_filter(d_img, d_out, w, h, d_taps + 65 * 65, 2, 1, stream))) break;
         if (hipGetLastError() != hipSuccess) { rc = 1; set_error("pt_post_chain: launch failed"); break; }
     } while (0);

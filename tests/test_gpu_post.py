@@ -22,6 +22,35 @@ def test_normal_filter(pt, oracle, ksize, sigma):
         assert np.abs(got - want).max() <= 1e-5
 
 
+def test_bloom_sized_gaussian_runs_as_two_passes(pt, oracle):
+    """65x65 sigma-10 table (an outer product: the library filters it as a row and a column pass) on an
+    image narrower than the window in one direction, sparse HDR input like the thresholded bloom layer."""
+    rng = np.random.default_rng(5)
+    taps = oracle.make_gaussian(32, 10.0)
+    for (h, w) in ((70, 150), (40, 300), (9, 33)):
+        img = _img(rng, h, w, scale=40.0)
+        img[img < 36] = 0
+        got = pt.apply_filter_host(img, taps)
+        want = oracle.apply_filter(img, taps, n_threads=8)
+        # 4225 fp32 additions per pixel in a different order: a few 1e-6 relative either way
+        assert np.abs(got - want).max() <= 1e-5 * float(want.max()), (h, w)
+
+
+def test_taps_that_are_not_an_outer_product(pt, oracle):
+    rng = np.random.default_rng(6)
+    img = _img(rng, 37, 53)
+    taps = rng.random((7, 7), dtype=np.float32) + 0.05
+    got = pt.apply_filter_host(img, taps)
+    want = oracle.apply_filter(img, taps, n_threads=8)
+    assert np.abs(got - want).max() <= 1e-5
+    plus = np.zeros((5, 5), np.float32)      # zero taps: a "plus" shape has rank 2
+    plus[2, :] = 1.0
+    plus[:, 2] = 1.0
+    got = pt.apply_filter_host(img, plus)
+    want = oracle.apply_filter(img, plus, n_threads=8)
+    assert np.abs(got - want).max() <= 1e-5
+
+
 def test_mean_filter_and_hdr_input(pt, oracle):
     rng = np.random.default_rng(3)
     img = _img(rng, 50, 61, scale=40.0)
