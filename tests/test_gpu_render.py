@@ -148,6 +148,27 @@ def test_launch_choices_do_not_change_the_image(pt, scenes):
     t.close()
 
 
+def test_scene_without_entities_is_the_environment(pt, oracle, scenes):
+    """No geometry at all: every path is one segment that ends in the environment map (smoothed and
+    not), and a scene with neither geometry nor environment renders black."""
+    hdri = scenes.procedural_hdri(256, 128)
+    cam = dict(position=(0, 0, 0), direction=(0.3, 0.2, 1.0), res=(64, 40), focal_length=1.2, aperture=0.5, focus_distance=10.0)
+    for smooth in (True, False):
+        desc = dict(name="sky", materials=[], entities=[], camera=scenes._camera(**cam),
+                    hdri=dict(rgb=hdri, exposure=1.5, contrast=1.0, rot=0.4, smooth=smooth))
+        g, cam_g, c, cam_c = _pair(pt, oracle, scenes, desc)
+        img_g, cnt = pt.render_image(g, cam_g, 16, seed=9, want_counters=True)
+        img_c, cnt_c = c.render(cam_c, 9, 0, 16, n_threads=4)
+        assert cnt["paths"] == cnt["segments"] == cnt["env_lookups"] == 64 * 40 * 16
+        assert cnt["tri_tests"] == cnt["node_visits"] == cnt["aabb_tests"] == 0
+        assert _rmse(img_g, img_c) <= 2e-3 * float(np.sqrt(np.mean(img_c.astype(np.float64) ** 2)))
+        g.close()
+    desc = dict(name="void", materials=[], entities=[], camera=scenes._camera(**cam), hdri=None)
+    g, cam_g = pt.scene_from_description(desc)
+    assert not pt.render_image(g, cam_g, 4).any()
+    g.close()
+
+
 def test_render_edge_cases(pt, scenes):
     desc = scenes.cornellbox_scene(res=(40, 24))
     g, cam = pt.scene_from_description(desc)

@@ -131,6 +131,41 @@ def test_odd_runs_and_pair_tails(pt, oracle):
             g.close()
 
 
+def test_deepest_octree_and_many_entities(pt, oracle, scenes):
+    """The depth limit (10 levels: the longest per-lane stack and the full width of the path word) next
+    to thirty spheres and a few brute-force meshes, so that every lane works through a long entity list."""
+    rng = np.random.default_rng(91)
+    pos, faces, uv = scenes.statue_mesh(1500)
+    tri = scenes.tri6(faces, faces)
+    c0 = pos.mean(axis=0)
+    ext = float(np.abs(pos - c0).max())
+    g, c = pt.Scene(0), oracle.OracleScene()
+    for s in (g, c):
+        m = s.add_material()
+        s.add_mesh(pos, tri, m, uvs=uv, octree_depth=10)
+    centers = (c0 + rng.normal(size=(30, 3)) * ext).astype(np.float32)
+    soups = [(c0 + rng.normal(size=(9, 3)) * ext).astype(np.float32) for _ in range(4)]
+    soup_tri = np.concatenate([np.arange(9, dtype=np.int32).reshape(-1, 3), np.full((3, 3), -1, np.int32)], axis=1)
+    for s in (g, c):
+        m = s.add_material()
+        for k in range(30):
+            s.add_sphere(centers[k], 0.05 * ext * (1 + k % 4), m)
+        for sp in soups:
+            s.add_mesh(sp, soup_tri, m, octree_depth=0)
+    g.commit()
+    rays = _random_rays(rng, 6000, c0, 1.2 * ext)
+    hg, lg, cg = g.trace(rays, log_stride=64)
+    hc, lc, cc = c.trace(rays, log_stride=64)
+    _assert_hits_equal(hg, hc)
+    assert np.array_equal(lg, lc)
+    for k in ("segments", "aabb_tests", "node_visits", "tri_tests"):
+        assert cg[k] == cc[k], k
+    assert len(np.unique(hg["entity"])) > 10
+    info = g.octree_info(0)
+    assert info["nodes_per_depth"][10] > 0
+    g.close()
+
+
 def test_empty_and_device_resident_buffers(teapot_pair, pt):
     g, c, desc = teapot_pair
     hits, _, cnt = g.trace(np.zeros((0, 6), np.float32))
