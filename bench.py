@@ -152,6 +152,15 @@ def main():
             traffic, traffic_source = int(tj["traffic_bytes_per_launch"]), "profiles/r1/traffic.json"
     except (OSError, ValueError, KeyError):
         pass
+    # VALU utilisation and cache rates of the same workload, from the committed counter passes (same rule as traffic)
+    pmc = None
+    try:
+        with open(os.path.join(REPO, "profiles", "r1", "pmc_ratios.json")) as f:
+            pj = json.load(f)
+        if pj.get("workload") == workload_name and world == 1:
+            pmc = {k: v for k, v in pj.items() if k not in ("workload",)}
+    except (OSError, ValueError):
+        pass
     roofline = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic, "traffic_source": traffic_source,
                 "kernel": "render_kernel", "kernel_ms": round(k_ms, 3), "algorithmic_bytes_per_launch": int(alg_bytes)}
@@ -199,7 +208,7 @@ def main():
             "time_to_spp_s": round(ms_per_step / 1000.0, 4),
             "msegments_per_s": round(total_counters["segments"] / (ms_per_step / 1000.0) / 1e6, 2),
             "counters": total_counters, "schedule": schedule, "launch": launch,
-            "roofline": roofline, "cpu_baseline": cpu_baseline,
+            "roofline": roofline, "pmc": pmc, "cpu_baseline": cpu_baseline,
             "post_chain_ms": None if post_ms is None else round(post_ms, 2),
             "scene_gen_s": round(t_gen, 2), "scene_build_upload_s": round(t_upload, 2),
             "scene_device_bytes": scene.device_bytes(),
