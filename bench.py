@@ -33,6 +33,16 @@ B_ENV = 48                   # bilinear HDRI lookup: 4 texels x 12 B
 B_ENTITY = 128               # entity record + AABB per (segment, entity)
 
 
+VALU_PEAK_TFLOPS = 157.3       # fp32 vector peak of one MI355X (256 CUs x 128 lanes x 2 flop x 2.4 GHz)
+
+
+def algorithmic_flops(counters, n_mesh_entities):
+    """Useful fp32 operations of one launch: 50 per triangle test, 25 per node visit, per segment a 24-flop slab test
+    for every mesh entity and about 150 of shading."""
+    return (counters["tri_tests"] * 50 + counters["node_visits"] * 25
+            + counters["segments"] * (24 * n_mesh_entities + 150))
+
+
 def algorithmic_bytes(counters, n_pixels, n_slices, n_entities):
     hits = counters["segments"] - counters["env_lookups"] if counters["env_lookups"] else counters["segments"]
     return (counters["node_visits"] * B_NODE + counters["tri_tests"] * B_TRI + hits * B_SHADE
@@ -152,6 +162,13 @@ def main():
             traffic, traffic_source = int(tj["traffic_bytes_per_launch"]), "profiles/r1/traffic.json"
     except (OSError, ValueError, KeyError):
         pass
+    # the second ceiling: useful fp32 operations against the vector peak (low by construction: the kernel saturates
+    # instruction issue with 37 % of the lanes active, and most instructions are compares, selects and address work)
+    n_mesh = sum(1 for e in desc["entities"] if e["kind"] == "mesh")
+    alg_flops = algorithmic_flops(counters, n_mesh)
+    tflops = alg_flops / (k_ms / 1000.0) / 1e12 if k_ms > 0 else 0.0
+    valu_roofline = {"achieved": round(tflops, 3), "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tflops / VALU_PEAK_TFLOPS, 5),
+                     "algorithmic_flops_per_launch": int(alg_flops)}
     # VALU utilisation and cache rates of the same workload, from the committed counter passes (same rule as traffic)
     pmc = None
     try:
@@ -208,7 +225,7 @@ def main():
             "time_to_spp_s": round(ms_per_step / 1000.0, 4),
             "msegments_per_s": round(total_counters["segments"] / (ms_per_step / 1000.0) / 1e6, 2),
             "counters": total_counters, "schedule": schedule, "launch": launch,
-            "roofline": roofline, "pmc": pmc, "cpu_baseline": cpu_baseline,
+            "roofline": roofline, "valu_roofline": valu_roofline, "pmc": pmc, "cpu_baseline": cpu_baseline,
             "post_chain_ms": None if post_ms is None else round(post_ms, 2),
             "scene_gen_s": round(t_gen, 2), "scene_build_upload_s": round(t_upload, 2),
             "scene_device_bytes": scene.device_bytes(),
