@@ -147,7 +147,7 @@ def main():
     value = paths_per_step / (ms_per_step / 1000.0) / 1e6
 
     # roofline of the dominant kernel (this rank's launch): algorithmic bytes / measured kernel time
-    plan_slices = n_split * min(32, max(1, (-(-(s_end - s_begin) // n_split) + 31) // 32))
+    plan_slices = n_split * min(max(1, 64 // n_split), max(1, (-(-(s_end - s_begin) // n_split) + 7) // 8))   # make_slice_plan
     k_ms = float(np.mean(kernel_ms)) if kernel_ms else float("nan")
     alg_bytes = algorithmic_bytes(counters, n_pixels, plan_slices, n_entities)
     achieved = alg_bytes / (k_ms / 1000.0) / 1e9 if k_ms > 0 else 0.0
