@@ -183,6 +183,7 @@ def main():
                 "kernel": "render_kernel", "kernel_ms": round(k_ms, 3), "algorithmic_bytes_per_launch": int(alg_bytes)}
 
     cpu_baseline = None
+    parity = None
     post_ms = None
     if rank == 0:
         # post-processing (reported separately): the reference's fixed chain, device resident
@@ -208,8 +209,14 @@ def main():
             t1 = time.perf_counter() - tc
             n_cpu = int(max(1, min(256, round(15.0 / max(t1, 1e-3)))))
             tc = time.perf_counter()
-            _, ccnt = osc.render(ocam, 1337, 1, 1 + n_cpu, rows=rows, n_threads=cores)
+            img_c, ccnt = osc.render(ocam, 1337, 1, 1 + n_cpu, rows=rows, n_threads=cores)
             tn = time.perf_counter() - tc
+            # the same samples on the GPU: full-frame check of the HIP path against the oracle (untimed)
+            img_g = ptamd.render_image(scene, cam, n_cpu, seed=1337, sample_begin=1, device=dev)
+            diff = (img_g.astype(np.float64) - img_c.astype(np.float64)) / n_cpu
+            rms = float(np.sqrt(np.mean((img_c.astype(np.float64) / n_cpu) ** 2)))
+            parity = {"rmse_over_rms": round(float(np.sqrt(np.mean(diff ** 2))) / max(rms, 1e-30), 6), "spp": n_cpu,
+                      "pixels_differing": int((np.abs(diff).max(axis=-1) > 1e-4 * rms).sum()), "pixels": n_pixels}
             cpu_baseline = {"value": round(n_pixels * n_cpu / tn / 1e6, 4), "unit": "Mpaths/s", "cores": cores, "kind": "port",
                             "sample": f"full {res[0]}x{res[1]} frame, {n_cpu} spp, {cores} threads, {tn:.1f} s"}
 
@@ -225,7 +232,7 @@ def main():
             "time_to_spp_s": round(ms_per_step / 1000.0, 4),
             "msegments_per_s": round(total_counters["segments"] / (ms_per_step / 1000.0) / 1e6, 2),
             "counters": total_counters, "schedule": schedule, "launch": launch,
-            "roofline": roofline, "valu_roofline": valu_roofline, "pmc": pmc, "cpu_baseline": cpu_baseline,
+            "roofline": roofline, "valu_roofline": valu_roofline, "pmc": pmc, "cpu_baseline": cpu_baseline, "parity_vs_oracle": parity,
             "post_chain_ms": None if post_ms is None else round(post_ms, 2),
             "scene_gen_s": round(t_gen, 2), "scene_build_upload_s": round(t_upload, 2),
             "scene_device_bytes": scene.device_bytes(),
