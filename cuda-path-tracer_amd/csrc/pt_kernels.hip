@@ -210,11 +210,13 @@ __device__ __forceinline__ void flush_stat(unsigned long long *dst, uint32_t v) 
 #define PT_DONE_QUOTA 12
 #endif
 static constexpr int kDoneQuota = PT_DONE_QUOTA;
-/* The render kernel is built twice: for 6 waves per SIMD (80 registers; the octree walk and the
- * triangle test fit, shading spills) and for 4 (128 registers, almost no spills).  Scenes dominated by
- * traversal gain from the extra waves, scenes dominated by entity set-up and shading lose. */
+/* The render kernel is built twice: for 5 waves per SIMD (96 registers; the octree walk and the
+ * triangle test fit, the path state spills around the shading code) and for 4 (128 registers, almost
+ * no spills).  Scenes dominated by traversal gain from the extra waves, scenes dominated by entity
+ * set-up and shading lose.  (6 waves / 80 registers: equal on the north-star scene, 4 % slower on
+ * the larger meshes; 7 and more spill inside the walk.) */
 #ifndef PT_WAVES_HEAVY
-#define PT_WAVES_HEAVY 6
+#define PT_WAVES_HEAVY 5
 #endif
 #ifndef PT_WAVES_LIGHT
 #define PT_WAVES_LIGHT 4

@@ -153,7 +153,7 @@ int pt_render_accumulate(pt_scene *scene, const pt_camera *camera, uint32_t seed
                          pt_counters *counters, void *stream);
 /* Launch choices (no counterpart in the reference).  The render kernel has two launch choices that
  * change how a wave schedules its lanes and nothing a path computes (images are bit-identical under
- * all of them): the kernel build (0 = light: 4 waves per SIMD, 1 = heavy: 6 waves, fewer registers)
+ * all of them): the kernel build (0 = light: 4 waves per SIMD, 1 = heavy: 5 waves, fewer registers)
  * and the quorum (how many of a wave's 64 lanes must have finished their ray before the wave leaves
  * the geometry blocks to shade and refill them: high where shading dominates, low inside deep
  * trees).  pt_scene_commit picks defaults from the scene; pt_scene_set_launch fixes a choice for
