@@ -212,11 +212,15 @@ def main():
             img_c, ccnt = osc.render(ocam, 1337, 1, 1 + n_cpu, rows=rows, n_threads=cores)
             tn = time.perf_counter() - tc
             # the same samples on the GPU: full-frame check of the HIP path against the oracle (untimed)
-            img_g = ptamd.render_image(scene, cam, n_cpu, seed=1337, sample_begin=1, device=dev)
+            # (with the counting build of the kernel, so that its work counters are checked as well and the timed
+            # kernel's profile holds nothing but the warm-up and timed launches)
+            img_g, gcnt = ptamd.render_image(scene, cam, n_cpu, seed=1337, sample_begin=1, device=dev, want_counters=True)
             diff = (img_g.astype(np.float64) - img_c.astype(np.float64)) / n_cpu
             rms = float(np.sqrt(np.mean((img_c.astype(np.float64) / n_cpu) ** 2)))
             parity = {"rmse_over_rms": round(float(np.sqrt(np.mean(diff ** 2))) / max(rms, 1e-30), 6), "spp": n_cpu,
-                      "pixels_differing": int((np.abs(diff).max(axis=-1) > 1e-4 * rms).sum()), "pixels": n_pixels}
+                      "pixels_differing": int((np.abs(diff).max(axis=-1) > 1e-4 * rms).sum()), "pixels": n_pixels,
+                      "counters_rel_diff": {k: round(abs(gcnt[k] - ccnt[k]) / max(ccnt[k], 1), 7)
+                                            for k in ("paths", "segments", "node_visits", "tri_tests", "env_lookups", "tex_fetches")}}
             cpu_baseline = {"value": round(n_pixels * n_cpu / tn / 1e6, 4), "unit": "Mpaths/s", "cores": cores, "kind": "port",
                             "sample": f"full {res[0]}x{res[1]} frame, {n_cpu} spp, {cores} threads, {tn:.1f} s"}
 

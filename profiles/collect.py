@@ -1,0 +1,92 @@
+#!/usr/bin/env python3
+"""Copies the judged files of one profiling run from gpurun_out/ into profiles/<round>/.
+
+usage: profiles/collect.py <tag> <round-dir>      e.g.  profiles/collect.py r1j profiles/r1
+Expects gpurun_out/prof_<tag>/ (profiles/run_profile.sh with FULL_TRAFFIC=1), gpurun_out/bench_default_<tag>.json and,
+optionally, gpurun_out/cfg_<workload>.json for the five configurations.  Writes kernel_stats_<tag>.csv, bench_line_<tag>.json,
+bench_default_<tag>.json, summary_<tag>.json, configs_<tag>.json and refreshes traffic.json / pmc_ratios.json (the two files
+bench.py reads)."""
+import collections
+import csv
+import glob
+import json
+import os
+import shutil
+import subprocess
+import sys
+
+tag, out = sys.argv[1], sys.argv[2]
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+prof = os.path.join(root, "gpurun_out", f"prof_{tag}")
+
+
+def newest(pattern):
+    files = sorted(glob.glob(pattern), key=os.path.getmtime)
+    if not files:
+        raise SystemExit(f"nothing matches {pattern}")
+    return files[-1]
+
+
+shutil.copy(newest(f"{prof}/trace/*/*kernel_stats.csv"), f"{out}/kernel_stats_{tag}.csv")
+shutil.copy(f"{prof}/trace_bench.json", f"{out}/bench_line_{tag}.json")
+shutil.copy(os.path.join(root, "gpurun_out", f"bench_default_{tag}.json"), f"{out}/bench_default_{tag}.json")
+with open(f"{out}/summary_{tag}.json", "w") as f:
+    subprocess.run([sys.executable, os.path.join(root, "profiles", "summarize.py"), prof], stdout=f, check=True)
+
+bench = json.load(open(f"{out}/bench_line_{tag}.json"))
+workload = bench["config"]["workload"]
+
+
+def timed_kernel_counters(passes):
+    """Sums of each counter over the dispatches of the timed (non-counting) render kernel."""
+    acc, name = collections.defaultdict(float), None
+    for p in passes:
+        for r in csv.DictReader(open(newest(f"{prof}/pmc_{p}/*/*counter_collection.csv"))):
+            if "render_kernel<false" in r["Kernel_Name"]:
+                acc[r["Counter_Name"]] += float(r["Counter_Value"])
+                name = r["Kernel_Name"].split("(")[0].replace("void ptamd::", "")
+    return acc, name
+
+
+full, kname = timed_kernel_counters(["full_fetch", "full_write"])
+traffic = int(full["FETCH_SIZE"] * 1024 * 2 + full["WRITE_SIZE"] * 1024)
+json.dump({
+    "workload": workload, "kernel": kname,
+    "source": f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over `python3 bench.py --no-cpu-baseline --steps 1 "
+              f"--warmup 0`, profiles/run_profile.sh {tag} with FULL_TRAFFIC=1",
+    "FETCH_SIZE_KB": full["FETCH_SIZE"], "WRITE_SIZE_KB": full["WRITE_SIZE"],
+    "correction": "FETCH_SIZE x2 on gfx950 (128-byte requests tallied as 64 bytes); calibrated for streaming reads, this kernel "
+                  "gathers: treat as +-2x",
+    "note": "the image is 25 MB per slice: nearly all of the writes, and as much of the reads, are register spills of the "
+            "many-waves build around the shading code",
+    "traffic_bytes_per_launch": traffic}, open(f"{out}/traffic.json", "w"), indent=1)
+
+acc, kname = timed_kernel_counters(["sq1", "sq2", "tcc1", "tcc2", "tcp"])
+g = acc["GRBM_GUI_ACTIVE"] / 8
+json.dump({
+    "workload": workload, "kernel": kname,
+    "source": f"rocprofv3 --pmc passes of profiles/run_profile.sh {tag} (256-spp launch of the same scene), counters of the timed "
+              "kernel only",
+    "valu_busy": round(acc["SQ_ACTIVE_INST_VALU"] * 4 / (1024 * g), 3),
+    "active_lanes_per_valu_instruction": round(acc["SQ_THREAD_CYCLES_VALU"] / (64 * acc["SQ_ACTIVE_INST_VALU"]), 3),
+    "wait_for_issue_over_wave_cycles": round(acc["SQ_WAIT_INST_ANY"] / acc["SQ_WAVE_CYCLES"], 3),
+    "waitcnt_over_wave_cycles": round(acc["SQ_WAIT_ANY"] / acc["SQ_WAVE_CYCLES"], 3),
+    "l2_hit_rate": round(acc["TCC_HIT_sum"] / acc["TCC_REQ_sum"], 3),
+    "l1_miss_rate": round(acc["TCP_TCC_READ_REQ_sum"] / acc["TCP_TOTAL_CACHE_ACCESSES_sum"], 3),
+    "waves_per_simd": int(kname.split(",")[1].strip(" >"))}, open(f"{out}/pmc_ratios.json", "w"), indent=1)
+
+cfgs = []
+for w in ("cornellbox", "teapot", "dragon", "hcandersen", "synthetic"):
+    p = os.path.join(root, "gpurun_out", f"cfg_{w}.json")
+    if os.path.exists(p):
+        cfgs.append(json.load(open(p)))
+if cfgs:
+    json.dump(cfgs, open(f"{out}/configs_{tag}.json", "w"), indent=1)
+
+print("traffic TB", traffic / 1e12, json.load(open(f"{out}/pmc_ratios.json")))
+for line in open(f"{out}/kernel_stats_{tag}.csv"):
+    if "ptamd" in line:
+        print(line.strip()[:140])
+for d in cfgs:
+    print(d["config"]["workload"], d["value"], d["roofline"]["kernel_ms"], d["roofline"]["frac"], d["post_chain_ms"], d["scene_build_upload_s"], d["launch"])
+print("traced bench", bench["value"], bench["roofline"]["kernel_ms"])
