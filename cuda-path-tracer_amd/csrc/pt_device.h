@@ -91,6 +91,10 @@ struct TriLog {        /* optional per-ray record of the triangle-test sequence 
 #ifndef PT_KEEP_LEAF
 #define PT_KEEP_LEAF 2
 #endif
+/* triangle runs are tested by the whole wave together (leaf_coop) instead of lane by lane (leaf_block) */
+#ifndef PT_COOP_LEAF
+#define PT_COOP_LEAF 1
+#endif
 
 enum : int { M_ENTITY = 0, M_NODE = 1, M_LEAF = 2, M_DONE = 3, M_IDLE = 4 };
 
@@ -427,13 +431,174 @@ __device__ __forceinline__ void leaf_block(const PtSceneDev &sc, Lane &L, Stats 
 }
 
 /*
+ * Cooperative LEAF phase.  In leaf_block a lane works through its own run, two records per trip, while the
+ * lanes in other states wait: with the lanes of a wave split between the octree walk and triangle runs of
+ * very different lengths, a trip has well under half of its lanes active.  Here the pending records of ALL
+ * lanes in M_LEAF are laid end to end and dealt out, one pair per lane and trip, to all 64 lanes of the
+ * wave whatever their own state: lane w of trip k takes pair 64k+w of the concatenation, finds the lane
+ * that owns it, fetches that lane's ray through the cross-lane network and runs the same packed test
+ * (pre-filter, then the exact IEEE sequence for candidates) against the owner's closest distance as it
+ * was when the phase began.  Every run is finished when the phase ends (runs longer than kCoopMaxPairs
+ * continue in the next phase), so the owners return to the walk together.
+ *
+ * Result.  Testing a run one by one accepts a test iff 0 < t < closest-so-far, so what the run leaves
+ * behind is the smallest accepted t, the earliest record on ties.  The candidates here are the tests with
+ * 0 < t < the closest distance at the start of the run, and the owner takes the minimum of (t, position in
+ * the run) over them -- an LDS 64-bit unsigned minimum, positive floats ordering like their bit patterns:
+ * the same hit, bit for bit, and "some test of the run was accepted" is "there is a candidate".
+ *
+ * Per-wave LDS: the best key and its barycentrics per owner, the table rank-of-run -> owner, and one bit
+ * per pair position where a run starts.
+ */
+static constexpr uint32_t kCoopMaxPairs = 16;     /* pairs per lane and phase: at most 1024 per phase */
+struct CoopLds {
+    unsigned long long res[64];
+    float win[64][2];
+    uint32_t own[64];
+    unsigned long long starts[kCoopMaxPairs];
+};
+
+__device__ __forceinline__ uint32_t lanes_below(unsigned long long m) {
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+}
+__device__ __forceinline__ float lane_read(float v, int src) { return __int_as_float(__builtin_amdgcn_ds_bpermute(src << 2, __float_as_int(v))); }
+__device__ __forceinline__ uint32_t lane_read(uint32_t v, int src) { return (uint32_t)__builtin_amdgcn_ds_bpermute(src << 2, (int)v); }
+__device__ __forceinline__ void wave_lds_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+template <bool STATS>
+__device__ __forceinline__ void leaf_coop(const PtSceneDev &sc, Lane &L, Stats &st, CoopLds *C, int lane) {
+    const bool mine = L.mode == M_LEAF;
+    const uint32_t my_left = mine ? L.tri_left : 0u;
+    const uint32_t my_pairs = (my_left + 1u) >> 1;
+    const uint32_t np = min(my_pairs, kCoopMaxPairs);
+    /* exclusive prefix and total of np over the wave, bit plane by bit plane (np <= 16) */
+    uint32_t excl = 0, T = 0;
+#pragma unroll
+    for (int b = 0; b < 5; b++) {
+        const unsigned long long m = __ballot(((np >> b) & 1u) != 0u);
+        excl += lanes_below(m) << b;
+        T += (uint32_t)__popcll(m) << b;
+    }
+    const unsigned long long runs = __ballot(np != 0u);
+    if (lane < (int)kCoopMaxPairs) C->starts[lane] = 0ull;
+    C->res[lane] = ~0ull;
+    wave_lds_fence();
+    if (np != 0u) {
+        atomicOr(&C->starts[excl >> 6], 1ull << (excl & 63u));
+        C->own[lanes_below(runs)] = (uint32_t)lane | (excl << 8);
+    }
+    wave_lds_fence();
+    const uint32_t my_cur = L.tri_cur;
+    const float my_bt = L.best.t;
+    const int n_words = (int)((T + 63u) >> 6);
+    uint32_t base = 0;
+#pragma nounroll
+    for (int k = 0; k < n_words; k++) {
+        unsigned long long m = C->starts[k];
+        m = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(m >> 32)) << 32) |
+            (uint32_t)__builtin_amdgcn_readfirstlane((int)m);
+        const uint32_t g = (uint32_t)(64 * k + lane);
+        const bool act = g < T;
+        /* the run pair g belongs to: the last one that starts at or before g */
+        const uint32_t r = base + lanes_below(m) + (uint32_t)((m >> lane) & 1ull) - 1u;
+        base += (uint32_t)__popcll(m);
+        const uint32_t ow = C->own[r & 63u];
+        const int owner = (int)(ow & 63u);
+        const uint32_t j = g - (ow >> 8);
+        const float sox = lane_read(L.o.x, owner), soy = lane_read(L.o.y, owner), soz = lane_read(L.o.z, owner);
+        const float sdx = lane_read(L.d.x, owner), sdy = lane_read(L.d.y, owner), sdz = lane_read(L.d.z, owner);
+        const float bt0 = lane_read(my_bt, owner);
+        const uint32_t o_cur = lane_read(my_cur, owner), o_left = lane_read(my_left, owner);
+        if (STATS) st.leaf_trips++;
+        if (act) {
+            if (STATS) st.leaf_lanes++;
+            const uint32_t idx = o_cur + j * (uint32_t)sizeof(PtTriPair);
+            const bool two = !((o_left & 1u) && j == ((o_left + 1u) >> 1) - 1u);
+            const float4 *q = reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(sc.tris) + idx);
+            const float4 r0 = q[0], r1 = q[1], r2 = q[2], r3 = q[3], r4 = q[4];
+            if (STATS) st.tri_tests += two ? 2u : 1u;
+            const f2 v0x = {r0.x, r0.y}, v0y = {r0.z, r0.w}, v0z = {r1.x, r1.y};
+            const f2 e1x = {r1.z, r1.w}, e1y = {r2.x, r2.y}, e1z = {r2.z, r2.w};
+            const f2 e2x = {r3.x, r3.y}, e2y = {r3.z, r3.w}, e2z = {r4.x, r4.y};
+            const f2 dx = {sdx, sdx}, dy = {sdy, sdy}, dz = {sdz, sdz};
+            const f2 px = (dy * e2z) - (dz * e2y), py = (dz * e2x) - (dx * e2z), pz = (dx * e2y) - (dy * e2x);
+            const f2 det = (e1x * px + e1y * py) + e1z * pz;
+            const f2 ox = {sox, sox}, oy = {soy, soy}, oz = {soz, soz};
+            const f2 tx = ox - v0x, ty = oy - v0y, tz = oz - v0z;
+            const f2 qx = (ty * e1z) - (tz * e1y), qy = (tz * e1x) - (tx * e1z), qz = (tx * e1y) - (ty * e1x);
+            const f2 un = (tx * px + ty * py) + tz * pz;
+            const f2 vn = (dx * qx + dy * qy) + dz * qz;
+            const f2 tn = (e2x * qx + e2y * qy) + e2z * qz;
+            const f2 ri = {__builtin_amdgcn_rcpf(det.x), __builtin_amdgcn_rcpf(det.y)};
+            const f2 ua = un * ri, va = vn * ri, ta = tn * ri;
+            const f2 uv = ua + va;
+            const float far = bt0 * 1.00001f;
+            uint32_t pend = 0;
+            if (!(fabsf(det.x) < 0.000000001f) &&
+                !((ua.x < -0.00011f) || (ua.x > 1.00011f) || (va.x < -0.00011f) || (uv.x > 1.00012f) || (ta.x < -1e-30f) || (ta.x > far)))
+                pend = 1u;
+            if (two && !(fabsf(det.y) < 0.000000001f) &&
+                !((ua.y < -0.00011f) || (ua.y > 1.00011f) || (va.y < -0.00011f) || (uv.y > 1.00012f) || (ta.y < -1e-30f) || (ta.y > far)))
+                pend |= 2u;
+            float bt = bt0, bu = 0.f, bv = 0.f;
+            uint32_t slot = 0;
+            bool has = false;
+            while (pend != 0u) {
+                const bool second = !(pend & 1u);
+                pend &= second ? ~2u : ~1u;
+                const float det_s = second ? det.y : det.x, un_s = second ? un.y : un.x, vn_s = second ? vn.y : vn.x, tn_s = second ? tn.y : tn.x;
+                const float inv_det = 1.0f / det_s;
+                const float u = un_s * inv_det, v = vn_s * inv_det, t = tn_s * inv_det;
+                const bool acc = !(u < -0.0001f || u > 1.0001f) && !(v < -0.0001f || u + v > 1.0001f) && (t > 0 && t < bt);
+                bt = acc ? t : bt; bu = acc ? u : bu; bv = acc ? v : bv;
+                slot = acc ? (second ? 1u : 0u) : slot;
+                has = has || acc;
+            }
+            if (has) {
+                const unsigned long long key = ((unsigned long long)__float_as_uint(bt) << 32) | (unsigned long long)(2u * j + slot);
+                atomicMin(&C->res[owner], key);
+                wave_lds_fence();
+                if (*(volatile unsigned long long *)&C->res[owner] == key) {
+                    C->win[owner][0] = bu;
+                    C->win[owner][1] = bv;
+                }
+            }
+        }
+        wave_lds_fence();
+    }
+    if (np != 0u) {
+        const unsigned long long key = C->res[lane];
+        if (key != ~0ull) {
+            const uint32_t oi = (uint32_t)key;
+            const uint32_t off = my_cur + (oi >> 1) * (uint32_t)sizeof(PtTriPair);
+            L.best.t = __uint_as_float((uint32_t)(key >> 32));
+            L.best.bu = C->win[lane][0];
+            L.best.bv = C->win[lane][1];
+            L.best.entity = L.ent - 1;
+            L.best.tri = reinterpret_cast<const int32_t *>(reinterpret_cast<const char *>(sc.tris) + off)[18u + (oi & 1u)];
+            L.best.rec = (off >> 3) | (oi & 1u);
+            L.run_flags |= 1;
+        }
+        L.tri_cur = my_cur + np * (uint32_t)sizeof(PtTriPair);
+        L.tri_left = my_left - min(my_left, 2u * np);
+        if (L.tri_left == 0u) {
+            if ((L.run_flags & 2) && !(L.run_flags & 1)) L.mode = M_NODE;
+            else L.mode = next_entity_mode(sc, L);
+        }
+    }
+}
+
+/*
  * Runs the geometry blocks until no lane of the wave is in M_ENTITY / M_NODE / M_LEAF any more, or
  * until at least `done_quota` lanes wait in M_DONE (so the caller can shade / refill them together).
  * The block with the most waiting lanes runs next, for a few trips while it stays well filled.
  */
 template <bool STATS, bool LOG>
 __device__ __forceinline__ void trace_wave(const PtSceneDev &sc, Lane &L, Stats &st, TriLog &lg, float4 *stack, uint32_t *stack1,
-                                           int stride, int done_quota) {
+                                           int stride, int done_quota, CoopLds *coop, int lane) {
     for (;;) {
         const int n_ent = __popcll(__ballot(L.mode == M_ENTITY));
         const int n_node = __popcll(__ballot(L.mode == M_NODE));
@@ -452,6 +617,8 @@ __device__ __forceinline__ void trace_wave(const PtSceneDev &sc, Lane &L, Stats 
                 if (STATS) st.node_trips++;
                 if (L.mode == M_NODE) { if (STATS) st.node_lanes++; node_block<STATS>(sc, L, st, stack, stack1, stride); }
             } while (++trips < PT_TRIPS && PT_KEEP_NODE * __popcll(__ballot(L.mode == M_NODE)) >= n_node);
+        } else if (!LOG && PT_COOP_LEAF) {
+            leaf_coop<STATS>(sc, L, st, coop, lane);
         } else {
             int trips = 0;
 #pragma nounroll

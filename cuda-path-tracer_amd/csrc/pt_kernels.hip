@@ -22,6 +22,12 @@ static constexpr int kBlock = 256;
  * workgroup's lanes; the walk pushes at levels 0 .. depth-2 (children of level depth-1 nodes are leaves) */
 __host__ __device__ static inline int stack_levels(int max_depth) { return max_depth > 1 ? max_depth - 1 : 1; }
 
+/* dynamic LDS of a workgroup: the stack frames (16-byte words, then 4-byte words), then one CoopLds per wave */
+__device__ __forceinline__ CoopLds *coop_area(float4 *lds, int max_depth) {
+    char *base = reinterpret_cast<char *>(lds) + (size_t)stack_levels(max_depth) * kBlock * (sizeof(float4) + sizeof(uint32_t));
+    return reinterpret_cast<CoopLds *>(base) + (threadIdx.x >> 6);
+}
+
 /* ------------------------------------------------------------------ shading (fast math allowed) */
 
 __device__ __forceinline__ float fast_rsq(float x) { return __builtin_amdgcn_rsqf(x); }
@@ -231,6 +237,7 @@ __global__ void __launch_bounds__(kBlock) trace_kernel(PtSceneDev sc, const floa
     extern __shared__ float4 lds_stack[];
     float4 *stack = lds_stack + threadIdx.x;
     uint32_t *stack1 = reinterpret_cast<uint32_t *>(lds_stack + stack_levels(sc.max_depth) * kBlock) + threadIdx.x;
+    CoopLds *coop = coop_area(lds_stack, sc.max_depth);
     Stats st;
     stats_zero(st);
     Lane L;
@@ -270,7 +277,7 @@ __global__ void __launch_bounds__(kBlock) trace_kernel(PtSceneDev sc, const floa
         }
         first = false;
         if (__ballot(L.mode != M_IDLE) == 0ull) break;
-        trace_wave<true, LOG>(sc, L, st, lg, stack, stack1, kBlock, kDoneQuota);
+        trace_wave<true, LOG>(sc, L, st, lg, stack, stack1, kBlock, kDoneQuota, coop, threadIdx.x & 63);
     }
     if (stats) {
         flush_stat(&stats[0], st.segments);
@@ -308,6 +315,7 @@ __global__ void __launch_bounds__(kBlock, WAVES) render_kernel(RenderParams P) {
     extern __shared__ float4 lds_stack[];
     float4 *stack = lds_stack + threadIdx.x;
     uint32_t *stack1 = reinterpret_cast<uint32_t *>(lds_stack + stack_levels(P.sc.max_depth) * kBlock) + threadIdx.x;
+    CoopLds *coop = coop_area(lds_stack, P.sc.max_depth);
     const int lane = threadIdx.x & 63;
     const int W = P.cam.res_x, H = P.cam.res_y;
     const int n_slices = P.plan.n_split * P.plan.slices_per_split;
@@ -455,7 +463,7 @@ __global__ void __launch_bounds__(kBlock, WAVES) render_kernel(RenderParams P) {
             if (__ballot(!done) == 0ull) break;      /* every lane is out of work: the grid drains */
             continue;                                /* e.g. lanes that drew an out-of-image slot ask again */
         }
-        trace_wave<STATS, false>(P.sc, L, st, lg, stack, stack1, kBlock, P.done_quota);
+        trace_wave<STATS, false>(P.sc, L, st, lg, stack, stack1, kBlock, P.done_quota, coop, lane);
     }
     if (STATS && P.stats) {
         flush_stat(&P.stats[0], st.segments);
@@ -519,7 +527,9 @@ SlicePlan make_slice_plan(int sample_begin, int sample_end, int n_split) {
     return p;
 }
 
-static size_t stack_bytes(int max_depth) { return (size_t)stack_levels(max_depth) * kBlock * (sizeof(float4) + sizeof(uint32_t)); }
+static size_t stack_bytes(int max_depth) {
+    return (size_t)stack_levels(max_depth) * kBlock * (sizeof(float4) + sizeof(uint32_t)) + (kBlock / 64) * sizeof(CoopLds);
+}
 
 int launch_trace(const PtSceneDev &sc, const float *d_rays, int64_t n, pt_hit *d_hits, int32_t *d_log, int log_stride,
                  unsigned long long *d_stats, hipStream_t stream) {

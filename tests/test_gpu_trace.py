@@ -23,6 +23,16 @@ def _assert_hits_equal(h_gpu, h_cpu):
         assert np.array_equal(_bits(h_gpu[f]), _bits(h_cpu[f])), f
 
 
+def _assert_unlogged_trace_equal(g, rays, h_cpu, c_cpu):
+    """Without a test log the triangle runs are tested by the whole wave together (a different code
+    path from the logged, lane-by-lane one): hits and work counters must be the same bits."""
+    hq, lq, cq = g.trace(rays, log_stride=0)
+    assert lq is None
+    _assert_hits_equal(hq, h_cpu)
+    for k in ("segments", "aabb_tests", "node_visits", "tri_tests"):
+        assert cq[k] == c_cpu[k], k
+
+
 def _random_rays(rng, n, center, radius):
     o = (center + rng.normal(size=(n, 3)) * radius).astype(np.float32)
     d = rng.normal(size=(n, 3)).astype(np.float32)
@@ -78,6 +88,7 @@ def test_teapot_primary_and_random_rays_vs_oracle(teapot_pair, oracle):
         assert np.array_equal(lg, lc), "triangle-test order differs"
         for k in ("segments", "aabb_tests", "node_visits", "tri_tests"):
             assert cg[k] == cc[k], k
+        _assert_unlogged_trace_equal(g, rays, hc, cc)
     assert (hg["entity"] >= 0).any()
 
 
@@ -104,6 +115,7 @@ def test_uv_mapped_smooth_mesh_and_depths(pt, oracle, scenes):
         assert np.array_equal(lg[:, 0], lc[:, 0])
         assert cg["tri_tests"] == cc["tri_tests"] and cg["node_visits"] == cc["node_visits"]
         assert (hg["entity"] == 1).any() and (hg["entity"] == 0).any()
+        _assert_unlogged_trace_equal(g, rays, hc, cc)
         g.close()
 
 
@@ -128,6 +140,7 @@ def test_odd_runs_and_pair_tails(pt, oracle):
             assert np.array_equal(lg, lc), (n_tris, depth)
             for k in ("segments", "aabb_tests", "node_visits", "tri_tests"):
                 assert cg[k] == cc[k], (n_tris, depth, k)
+            _assert_unlogged_trace_equal(g, rays, hc, cc)
             g.close()
 
 
@@ -161,6 +174,7 @@ def test_deepest_octree_and_many_entities(pt, oracle, scenes):
     for k in ("segments", "aabb_tests", "node_visits", "tri_tests"):
         assert cg[k] == cc[k], k
     assert len(np.unique(hg["entity"])) > 10
+    _assert_unlogged_trace_equal(g, rays, hc, cc)
     info = g.octree_info(0)
     assert info["nodes_per_depth"][10] > 0
     g.close()
