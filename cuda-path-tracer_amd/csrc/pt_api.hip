@@ -68,6 +68,7 @@ struct pt_scene {
     /* launch choices of the render kernel (defaults picked at commit, pt_scene_set_launch overrides) */
     bool heavy = false;        /* traversal-dominated scene: render with the many-waves build of the kernel */
     int quorum = 12;           /* finished lanes per wave that make it leave the geometry blocks to shade / refill */
+    int leaf_quota = 20;       /* triangle runs waiting per wave at which it tests them before walking on */
     bool build_fixed = false, quorum_fixed = false;   /* set by the caller or the environment: commit keeps them */
     PtSceneDev dev{};
     std::vector<void *> allocs;
@@ -422,18 +423,26 @@ int pt_scene_commit(pt_scene *scene) {
     }
     /* the quorum: a refill round (shading, new paths, their entity set-up) costs the same whatever the
      * number of lanes it serves, so it should serve many where it is expensive next to the walk that
-     * separates two rounds -- textured materials (measured optimum 40 of 64 lanes against 12: +5 %) and
-     * most of all scenes without any octree, where there is no walk at all (62: +34 %) -- and few
-     * inside deep trees, where lanes waiting for a refill idle through many walk steps */
+     * separates two rounds -- textured materials, and most of all scenes without any octree, where there
+     * is no walk at all (62: +34 %) -- and few inside deep trees, where lanes waiting for a refill idle
+     * through many walk steps.  The heavy build tests triangle runs with the whole wave, waiting lanes
+     * included, so waiting costs it less and its optimum lies higher (measured: 48 / 40 against 40 / 12) */
     if (!scene->quorum_fixed) {
         bool textured = false;
         for (const MaterialHost &m : scene->materials)
             for (int k = 0; k < 4; k++) textured = textured || !m.maps[k].empty();
-        scene->quorum = max_depth == 0 ? 62 : (textured ? 40 : 12);
+        if (max_depth == 0) scene->quorum = 62;
+        else if (scene->heavy) scene->quorum = textured ? 48 : 40;
+        else scene->quorum = textured ? 40 : 12;
     }
     if (const char *k = getenv("PTAMD_QUORUM")) {
         const int q = atoi(k);
         if (q >= 1 && q <= 64) { scene->quorum = q; scene->quorum_fixed = true; }
+    }
+
+    if (const char *k = getenv("PTAMD_LEAF_QUOTA")) {
+        const int q = atoi(k);
+        if (q >= 1 && q <= 65) scene->leaf_quota = q;
     }
 
     PT_HIP(hipMalloc((void **)&scene->d_tickets, (kMaxQueues + 1) * sizeof(uint32_t)));
@@ -589,6 +598,7 @@ int prepare_render(pt_scene *scene, const pt_camera *camera, uint32_t seed, int 
     p.tickets = scene->d_tickets;
     p.stats = nullptr;
     p.done_quota = scene->quorum;
+    p.leaf_quota = scene->leaf_quota;
     return 0;
 }
 

@@ -91,10 +91,7 @@ struct TriLog {        /* optional per-ray record of the triangle-test sequence 
 #ifndef PT_KEEP_LEAF
 #define PT_KEEP_LEAF 2
 #endif
-/* triangle runs are tested by the whole wave together (leaf_coop) instead of lane by lane (leaf_block) */
-#ifndef PT_COOP_LEAF
-#define PT_COOP_LEAF 1
-#endif
+
 
 enum : int { M_ENTITY = 0, M_NODE = 1, M_LEAF = 2, M_DONE = 3, M_IDLE = 4 };
 
@@ -596,9 +593,10 @@ __device__ __forceinline__ void leaf_coop(const PtSceneDev &sc, Lane &L, Stats &
  * until at least `done_quota` lanes wait in M_DONE (so the caller can shade / refill them together).
  * The block with the most waiting lanes runs next, for a few trips while it stays well filled.
  */
-template <bool STATS, bool LOG>
+template <bool STATS, bool LOG, bool COOP>
 __device__ __forceinline__ void trace_wave(const PtSceneDev &sc, Lane &L, Stats &st, TriLog &lg, float4 *stack, uint32_t *stack1,
-                                           int stride, int done_quota, CoopLds *coop, int lane) {
+                                           int stride, int done_quota, int leaf_quota, CoopLds *coop, int lane) {
+    static_assert(!(LOG && COOP), "the cooperative leaf phase keeps no test log");
     for (;;) {
         const int n_ent = __popcll(__ballot(L.mode == M_ENTITY));
         const int n_node = __popcll(__ballot(L.mode == M_NODE));
@@ -607,17 +605,21 @@ __device__ __forceinline__ void trace_wave(const PtSceneDev &sc, Lane &L, Stats 
         /* leave to shade / refill once the finished lanes are a quorum and no block has more lanes waiting */
         const int n_done = __popcll(__ballot(L.mode == M_DONE));
         if (n_done >= done_quota && n_done >= n_node && n_done >= n_leaf) return;
+        /* a cooperative leaf phase serves every waiting run with all 64 lanes: it runs as soon as `leaf_quota`
+         * runs wait (about enough pairs for a full trip), and the walk stops for it */
+        const bool leaf_first = COOP ? (n_leaf >= leaf_quota || n_leaf > n_node) : (n_leaf > n_node);
         if (n_ent >= n_node && n_ent >= n_leaf) {
             if (STATS) st.ent_trips++;
             if (L.mode == M_ENTITY) { if (STATS) st.ent_lanes++; entity_block<STATS>(sc, L, st); }
-        } else if (n_node >= n_leaf) {
+        } else if (!leaf_first) {
             int trips = 0;
 #pragma nounroll
             do {
                 if (STATS) st.node_trips++;
                 if (L.mode == M_NODE) { if (STATS) st.node_lanes++; node_block<STATS>(sc, L, st, stack, stack1, stride); }
-            } while (++trips < PT_TRIPS && PT_KEEP_NODE * __popcll(__ballot(L.mode == M_NODE)) >= n_node);
-        } else if (!LOG && PT_COOP_LEAF) {
+            } while (++trips < PT_TRIPS && PT_KEEP_NODE * __popcll(__ballot(L.mode == M_NODE)) >= n_node &&
+                     !(COOP && __popcll(__ballot(L.mode == M_LEAF)) >= leaf_quota));
+        } else if (COOP) {
             leaf_coop<STATS>(sc, L, st, coop, lane);
         } else {
             int trips = 0;

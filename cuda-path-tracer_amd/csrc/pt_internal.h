@@ -49,6 +49,7 @@ struct RenderParams {
     float *partials;             /* [n_split * slices_per_split][H*W][3] */
     unsigned long long *stats;   /* 7 counters, or null */
     int done_quota;              /* finished lanes per wave at which it leaves the geometry blocks to shade / refill */
+    int leaf_quota;              /* triangle runs waiting per wave at which it tests them before walking on */
 };
 
 /* kernel launchers (pt_kernels.hip); all asynchronous on `stream` */

@@ -216,6 +216,11 @@ __device__ __forceinline__ void flush_stat(unsigned long long *dst, uint32_t v) 
 #define PT_DONE_QUOTA 12
 #endif
 static constexpr int kDoneQuota = PT_DONE_QUOTA;
+/* triangle runs waiting in a wave at which it tests them (cooperative leaf phase) before walking on */
+#ifndef PT_LEAF_QUOTA
+#define PT_LEAF_QUOTA 20
+#endif
+static constexpr int kLeafQuota = PT_LEAF_QUOTA;
 /* The render kernel is built twice: for 5 waves per SIMD (96 registers; the octree walk and the
  * triangle test fit, the path state spills around the shading code) and for 4 (128 registers, almost
  * no spills).  Scenes dominated by traversal gain from the extra waves, scenes dominated by entity
@@ -277,7 +282,7 @@ __global__ void __launch_bounds__(kBlock) trace_kernel(PtSceneDev sc, const floa
         }
         first = false;
         if (__ballot(L.mode != M_IDLE) == 0ull) break;
-        trace_wave<true, LOG>(sc, L, st, lg, stack, stack1, kBlock, kDoneQuota, coop, threadIdx.x & 63);
+        trace_wave<true, LOG, !LOG>(sc, L, st, lg, stack, stack1, kBlock, kDoneQuota, kLeafQuota, coop, threadIdx.x & 63);
     }
     if (stats) {
         flush_stat(&stats[0], st.segments);
@@ -310,7 +315,7 @@ __device__ __forceinline__ void slice_range(const SlicePlan &pl, int slice, int 
     s1 = zb + (int)((M * (j + 1)) / pl.slices_per_split);
 }
 
-template <bool STATS, int WAVES>
+template <bool STATS, int WAVES, bool COOP>
 __global__ void __launch_bounds__(kBlock, WAVES) render_kernel(RenderParams P) {
     extern __shared__ float4 lds_stack[];
     float4 *stack = lds_stack + threadIdx.x;
@@ -463,7 +468,7 @@ __global__ void __launch_bounds__(kBlock, WAVES) render_kernel(RenderParams P) {
             if (__ballot(!done) == 0ull) break;      /* every lane is out of work: the grid drains */
             continue;                                /* e.g. lanes that drew an out-of-image slot ask again */
         }
-        trace_wave<STATS, false>(P.sc, L, st, lg, stack, stack1, kBlock, P.done_quota, coop, lane);
+        trace_wave<STATS, false, COOP>(P.sc, L, st, lg, stack, stack1, kBlock, P.done_quota, P.leaf_quota, coop, lane);
     }
     if (STATS && P.stats) {
         flush_stat(&P.stats[0], st.segments);
@@ -568,11 +573,11 @@ int launch_render(RenderParams p, int n_cu, int max_queues, bool heavy, hipStrea
     p.n_queues = (uint32_t)blocks;
     const dim3 grid((unsigned)blocks), block(kBlock);
     if (heavy) {
-        if (p.stats) hipLaunchKernelGGL((render_kernel<true, kWavesHeavy>), grid, block, lds, stream, p);
-        else hipLaunchKernelGGL((render_kernel<false, kWavesHeavy>), grid, block, lds, stream, p);
+        if (p.stats) hipLaunchKernelGGL((render_kernel<true, kWavesHeavy, true>), grid, block, lds, stream, p);
+        else hipLaunchKernelGGL((render_kernel<false, kWavesHeavy, true>), grid, block, lds, stream, p);
     } else {
-        if (p.stats) hipLaunchKernelGGL((render_kernel<true, kWavesLight>), grid, block, lds, stream, p);
-        else hipLaunchKernelGGL((render_kernel<false, kWavesLight>), grid, block, lds, stream, p);
+        if (p.stats) hipLaunchKernelGGL((render_kernel<true, kWavesLight, false>), grid, block, lds, stream, p);
+        else hipLaunchKernelGGL((render_kernel<false, kWavesLight, false>), grid, block, lds, stream, p);
     }
     PT_HIP(hipGetLastError());
     return 0;
