@@ -447,7 +447,11 @@ __device__ __forceinline__ void leaf_block(const PtSceneDev &sc, Lane &L, Stats 
  * Per-wave LDS: the best key and its barycentrics per owner, the table rank-of-run -> owner, and one bit
  * per pair position where a run starts.
  */
-static constexpr uint32_t kCoopMaxPairs = 16;     /* pairs per lane and phase: at most 1024 per phase */
+#ifndef PT_COOP_MAX_PAIRS
+#define PT_COOP_MAX_PAIRS 16
+#endif
+static constexpr uint32_t kCoopMaxPairs = PT_COOP_MAX_PAIRS;     /* pairs per lane and phase (a power of two): at most 64 times as many per phase */
+static constexpr int kCoopPlanes = 32 - __builtin_clz(PT_COOP_MAX_PAIRS);
 struct CoopLds {
     unsigned long long res[64];
     float win[64][2];
@@ -471,10 +475,10 @@ __device__ __forceinline__ void leaf_coop(const PtSceneDev &sc, Lane &L, Stats &
     const uint32_t my_left = mine ? L.tri_left : 0u;
     const uint32_t my_pairs = (my_left + 1u) >> 1;
     const uint32_t np = min(my_pairs, kCoopMaxPairs);
-    /* exclusive prefix and total of np over the wave, bit plane by bit plane (np <= 16) */
+    /* exclusive prefix and total of np over the wave, bit plane by bit plane */
     uint32_t excl = 0, T = 0;
 #pragma unroll
-    for (int b = 0; b < 5; b++) {
+    for (int b = 0; b < kCoopPlanes; b++) {
         const unsigned long long m = __ballot(((np >> b) & 1u) != 0u);
         excl += lanes_below(m) << b;
         T += (uint32_t)__popcll(m) << b;

@@ -573,8 +573,19 @@ int launch_render(RenderParams p, int n_cu, int max_queues, bool heavy, hipStrea
     p.n_queues = (uint32_t)blocks;
     const dim3 grid((unsigned)blocks), block(kBlock);
     if (heavy) {
-        if (p.stats) hipLaunchKernelGGL((render_kernel<true, kWavesHeavy, true>), grid, block, lds, stream, p);
-        else hipLaunchKernelGGL((render_kernel<false, kWavesHeavy, true>), grid, block, lds, stream, p);
+        /* deep octrees need so much LDS for their stacks that fewer workgroups fit than the registers of the
+         * 5-wave build allow: the builds for 4 and 3 waves per SIMD then have the larger register budget for
+         * the same residency (dragon-class scene at depth 7, four workgroups per CU: +7 % with 128 registers) */
+        if (per_cu >= kWavesHeavy) {
+            if (p.stats) hipLaunchKernelGGL((render_kernel<true, kWavesHeavy, true>), grid, block, lds, stream, p);
+            else hipLaunchKernelGGL((render_kernel<false, kWavesHeavy, true>), grid, block, lds, stream, p);
+        } else if (per_cu == 4) {
+            if (p.stats) hipLaunchKernelGGL((render_kernel<true, 4, true>), grid, block, lds, stream, p);
+            else hipLaunchKernelGGL((render_kernel<false, 4, true>), grid, block, lds, stream, p);
+        } else {
+            if (p.stats) hipLaunchKernelGGL((render_kernel<true, 3, true>), grid, block, lds, stream, p);
+            else hipLaunchKernelGGL((render_kernel<false, 3, true>), grid, block, lds, stream, p);
+        }
     } else {
         if (p.stats) hipLaunchKernelGGL((render_kernel<true, kWavesLight, false>), grid, block, lds, stream, p);
         else hipLaunchKernelGGL((render_kernel<false, kWavesLight, false>), grid, block, lds, stream, p);
