@@ -117,9 +117,10 @@ int pt_scene_set_hdri(pt_scene *scene, const float *rgb, int w, int h, float exp
                       float contrast, float rot_offset, int smooth);
 /* flattens every octree into the linear node / triangle-pair arrays and uploads the scene.  Also sets
  * the defaults of the two launch choices of the render kernel (see pt_scene_set_launch): the build --
- * many waves and few registers for scenes with a large octree, fewer waves otherwise -- and the
- * quorum (62 without any octree, 40 with textured materials, else 12); the environment variables
- * PTAMD_KERNEL = heavy | light and PTAMD_QUORUM = 1..64 fix them.  Limits: 2^29 octree nodes and
+ * heavy for scenes with a large octree, light otherwise -- and the quorum (62 without any octree; heavy
+ * build: 48 with textured materials, else 40; light build: 40 / 12); the environment variables
+ * PTAMD_KERNEL = heavy | light, PTAMD_QUORUM = 1..64 and PTAMD_LEAF_QUOTA = 1..65 (heavy build: triangle
+ * runs waiting in a wave at which it tests them, default 20) fix them.  Limits: 2^29 octree nodes and
  * 4 GiB of triangle pairs per scene. */
 int pt_scene_commit(pt_scene *scene);
 int pt_scene_octree_info(pt_scene *scene, int entity, pt_octree_info *info);
@@ -153,8 +154,9 @@ int pt_render_accumulate(pt_scene *scene, const pt_camera *camera, uint32_t seed
                          pt_counters *counters, void *stream);
 /* Launch choices (no counterpart in the reference).  The render kernel has two launch choices that
  * change how a wave schedules its lanes and nothing a path computes (images are bit-identical under
- * all of them): the kernel build (0 = light: 4 waves per SIMD, 1 = heavy: 5 waves, fewer registers)
- * and the quorum (how many of a wave's 64 lanes must have finished their ray before the wave leaves
+ * all of them): the kernel build (0 = light: 4 waves per SIMD, every lane tests the triangle runs of
+ * its own ray; 1 = heavy: up to 5 waves, fewer registers, and the triangle runs waiting in a wave are
+ * tested by all of its 64 lanes together) and the quorum (how many of a wave's 64 lanes must have finished their ray before the wave leaves
  * the geometry blocks to shade and refill them: high where shading dominates, low inside deep
  * trees).  pt_scene_commit picks defaults from the scene; pt_scene_set_launch fixes a choice for
  * this and later commits (kernel_build -1 / quorum 0 = leave as is); pt_scene_get_launch reports
