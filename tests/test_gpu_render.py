@@ -110,18 +110,28 @@ def test_simulated_ranks_equal_single_gpu(pt, scenes):
 
 
 def test_both_kernel_builds_give_identical_images(pt, scenes, monkeypatch):
-    """The render kernel exists in two register budgets (chosen per scene at commit, PTAMD_KERNEL
-    overrides): same arithmetic, same summation order -> identical bits, counters included."""
-    desc = scenes.hcandersen_scene(res=(96, 54), n_tris=6000, tex_res=128, hdri_res=(128, 64))
-    out = {}
-    for build in ("light", "heavy"):
-        monkeypatch.setenv("PTAMD_KERNEL", build)
-        g, cam = pt.scene_from_description(desc)
-        out[build] = pt.render_image(g, cam, 32, seed=3, want_counters=True)
-        g.close()
-    assert np.array_equal(out["light"][0].view(np.uint32), out["heavy"][0].view(np.uint32))
-    assert out["light"][1] == out["heavy"][1]
-    assert out["light"][0].max() > 0
+    """The render kernel exists in two builds (chosen per scene at commit, PTAMD_KERNEL overrides): the
+    light one tests every lane's triangle runs lane by lane, the heavy one hands the waiting runs of a
+    wave out to all of its lanes (at any leaf quota) and is instantiated for 5, 4 and 3 waves per SIMD
+    (deeper octrees leave LDS for fewer workgroups).  Same arithmetic, same summation order ->
+    identical bits, counters included."""
+    for depth in (6, 7, 9):
+        desc = scenes.hcandersen_scene(res=(96, 54), n_tris=6000, tex_res=128, hdri_res=(128, 64))
+        for e in desc["entities"]:
+            if e["kind"] == "mesh":
+                e["octree_depth"] = depth
+        out = {}
+        for build, leaf_quota in (("light", "20"), ("heavy", "20"), ("heavy", "1"), ("heavy", "65")):
+            monkeypatch.setenv("PTAMD_KERNEL", build)
+            monkeypatch.setenv("PTAMD_LEAF_QUOTA", leaf_quota)
+            g, cam = pt.scene_from_description(desc)
+            out[build, leaf_quota] = pt.render_image(g, cam, 32, seed=3, want_counters=True)
+            g.close()
+        ref = out["light", "20"]
+        assert ref[0].max() > 0
+        for k, v in out.items():
+            assert np.array_equal(ref[0].view(np.uint32), v[0].view(np.uint32)), (depth, k)
+            assert ref[1] == v[1], (depth, k)
 
 
 def test_launch_choices_do_not_change_the_image(pt, scenes):
