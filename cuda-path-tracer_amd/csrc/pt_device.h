@@ -24,7 +24,9 @@
  *
  * The kernel is bound by vector-instruction issue (a SIMD issues one wave64 VALU instruction per four
  * cycles), so the blocks are written for instruction count: the children a node's loop would step
- * through are listed once per node, branch-free; triangle tests run two at a time in packed fp32.
+ * through are listed once per node, branch-free; triangle tests run two at a time in packed fp32 --
+ * and for lane occupancy: triangle runs, the one part of a ray's work that is parallel in itself, are
+ * handed out to all lanes of the wave (leaf_coop), idle ones included.
  */
 #ifndef PT_DEVICE_H
 #define PT_DEVICE_H

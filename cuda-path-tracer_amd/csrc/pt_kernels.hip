@@ -3,14 +3,19 @@
  * kernel and the split-buffer compounding kernels (gfx950).
  *
  * Render kernel structure: a persistent grid (a few 256-thread workgroups per CU) whose waves pull
- * work items {8x8-pixel tile, sample slice} from one global ticket.  A lane owns one pixel of an
+ * work items {8x8-pixel tile, sample slice} from per-workgroup queues (contiguous ranges of the item
+ * space in macro-tile order; an empty queue steals from the next).  A lane owns one pixel of an
  * item and runs the slice's samples one after the other; every trip of the main loop advances each
  * lane's path by ONE segment (closest hit + shading).  A lane whose path ended starts its next
  * sample on the next trip, and a lane whose slice is finished immediately takes the next free
  * pixel of the wave's current item (or of a freshly pulled one), so terminated paths never leave
- * holes in the wave: the lanes stay compacted onto live rays until the ticket runs dry.  Each
+ * holes in the wave: the lanes stay compacted onto live rays until the queues run dry.  Each
  * (pixel, slice) sum is written exactly once by its owner to a partial buffer and the partials are
  * combined in fixed order afterwards -- no atomics on pixels, bit-reproducible images.
+ *
+ * The kernel is instantiated per register budget (waves per SIMD) and per leaf strategy: lane by lane
+ * (leaf_block) for small scenes, or the cooperative phase (leaf_coop: the waiting triangle runs of a
+ * wave are tested by all of its lanes) for scenes whose time goes into the octree.
  */
 #include "pt_device.h"
 #include "pt_internal.h"
