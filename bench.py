@@ -201,7 +201,7 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             sys.path.insert(0, os.path.join(REPO, "oracle"))
             import oracle_api as O
-            osc, ocam = S.build_oracle_scene(desc, O)
+            osc, ocam = O.scene_from_description(desc)
             cores = min(os.cpu_count() or 1, 16)
             rows = (0, res[1])
             tc = time.perf_counter()

@@ -77,6 +77,7 @@ struct pt_scene {
     DevBuf partials;                    /* render workspace, grown on demand */
     uint32_t *d_tickets = nullptr;      /* kMaxQueues work-queue cursors */
     unsigned long long *d_stats = nullptr;
+    bool stats_valid = false;           /* d_stats holds the scheduling counters of a counted render launch */
 
     bool profiling = false;             /* bracket the render kernel with HIP events */
     hipEvent_t ev_start = nullptr, ev_stop = nullptr;
@@ -136,6 +137,7 @@ void free_device_side(pt_scene *s) {
     if (s->ev_stop) (void)hipEventDestroy(s->ev_stop);
     s->ev_start = s->ev_stop = nullptr;
     s->ev_valid = false;
+    s->stats_valid = false;
     s->committed = false;
     s->bytes_nodes = s->bytes_tris = s->bytes_shade = s->bytes_tex = s->bytes_hdri = 0;
 }
@@ -447,6 +449,7 @@ int pt_scene_commit(pt_scene *scene) {
 
     PT_HIP(hipMalloc((void **)&scene->d_tickets, (kMaxQueues + 1) * sizeof(uint32_t)));
     PT_HIP(hipMalloc((void **)&scene->d_stats, 16 * sizeof(unsigned long long)));
+    PT_HIP(hipMemset(scene->d_stats, 0, 16 * sizeof(unsigned long long)));
     scene->committed = true;
     return 0;
 }
@@ -473,6 +476,7 @@ int pt_scene_octree_dump(pt_scene *scene, int entity, int32_t *out, int64_t cap,
     std::vector<int32_t> d;
     dump_octree(h.tree, d);
     *n_words = (int64_t)d.size();
+    if (out && cap < 0) PT_FAIL("pt_scene_octree_dump: negative capacity");
     if (out) memcpy(out, d.data(), sizeof(int32_t) * (size_t)std::min<int64_t>(cap, (int64_t)d.size()));
     return 0;
 }
@@ -501,6 +505,8 @@ int pt_trace_rays(pt_scene *scene, const float *rays, int64_t n, pt_hit *hits, i
     if (!rays || !hits) PT_FAIL("pt_trace_rays: null buffer");
     if (log && log_stride < 1) PT_FAIL("pt_trace_rays: log_stride must be >= 1");
     DeviceGuard g(scene->device);
+    if (!g.ok) PT_FAIL("pt_trace_rays: cannot select device");
+    if (counters) scene->stats_valid = false;      /* the query kernel overwrites the counter block */
     hipStream_t stream = (hipStream_t)stream_;
     const bool rays_dev = is_device_pointer(rays), hits_dev = is_device_pointer(hits);
     const bool log_dev = log ? is_device_pointer(log) : true;
@@ -625,6 +631,7 @@ int pt_render_accumulate(pt_scene *scene, const pt_camera *camera, uint32_t seed
         return 0;
     }
     DeviceGuard g(scene->device);
+    if (!g.ok) PT_FAIL("pt_render_accumulate: cannot select device");
     hipStream_t stream = (hipStream_t)stream_;
     const int64_t n_pixels = (int64_t)camera->res_x * camera->res_y;
     RenderParams p;
@@ -647,6 +654,7 @@ int pt_render_accumulate(pt_scene *scene, const pt_camera *camera, uint32_t seed
         PT_HIP(hipMemcpyAsync(h, scene->d_stats, sizeof h, hipMemcpyDeviceToHost, stream));
         PT_HIP(hipStreamSynchronize(stream));
         counters_from(h, counters);
+        scene->stats_valid = true;
     }
     return 0;
 }
@@ -670,7 +678,9 @@ int pt_scene_get_launch(pt_scene *scene, int *kernel_build, int *quorum) {
 int pt_scene_schedule_counters(pt_scene *scene, uint64_t out[8]) {
     if (!scene || !out) PT_FAIL("pt_scene_schedule_counters: null argument");
     if (!scene->committed) PT_FAIL("pt_scene_schedule_counters: scene not committed");
+    if (!scene->stats_valid) PT_FAIL("pt_scene_schedule_counters: no render launch with counters since the scene was committed");
     DeviceGuard g(scene->device);
+    if (!g.ok) PT_FAIL("pt_scene_schedule_counters: cannot select device");
     unsigned long long h[16];
     PT_HIP(hipMemcpy(h, scene->d_stats, sizeof h, hipMemcpyDeviceToHost));
     for (int i = 0; i < 8; i++) out[i] = h[7 + i];

@@ -154,7 +154,7 @@ def _mesh_normals(mode, pos, tri, vns, ni):
 
 
 def load_scene(path):
-    """Scene file -> (scene description for scene_from_description / build_oracle_scene, render settings)"""
+    """Scene file -> (scene description for ptamd.scene_from_description, render settings)"""
     base = os.path.dirname(os.path.abspath(path))
     with open(path) as f:
         doc = json.load(f)

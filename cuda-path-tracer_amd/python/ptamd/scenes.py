@@ -433,22 +433,3 @@ CONFIGS = {
     "synthetic": dict(builder=synthetic_scene, res=(3840, 2160), spp=4096),
 }
 
-
-def build_oracle_scene(desc, oracle_api):
-    """Feeds a scene description to the CPU oracle (test / baseline use only)."""
-    sc = oracle_api.OracleScene()
-    for m in desc["materials"]:
-        mid = sc.add_material(m["albedo"], m["specular"], m["emission"], m["smoothness"], m["smooth_shading"])
-        for which, data in m["maps"].items():
-            sc.set_map(mid, which, data)
-    for e in desc["entities"]:
-        if e["kind"] == "mesh":
-            sc.add_mesh(e["positions"], e["tri"], e["material"], normals=e["normals"], uvs=e["uvs"], octree_depth=e["octree_depth"])
-        else:
-            sc.add_sphere(e["center"], e["radius"], e["material"])
-    if desc.get("hdri"):
-        hd = desc["hdri"]
-        sc.set_hdri(hd["rgb"], hd["exposure"], hd["contrast"], hd["rot"], hd["smooth"])
-    c = desc["camera"]
-    cam = oracle_api.make_camera(c["position"], c["direction"], c["res"], c["focal_length"], c["aperture"], c["focus_distance"])
-    return sc, cam

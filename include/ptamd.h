@@ -148,7 +148,11 @@ int pt_camera_rays(int device, const pt_camera *camera, uint32_t seed, int sampl
  * split buffer z receives the samples of the z-th of n_split equal sub-ranges.  += semantics: the
  * caller zeroes the buffers before the first call.  Sample s of pixel p draws from the Philox
  * stream (seed; p, s), so the image does not depend on how samples are sharded over calls/GPUs
- * beyond floating-point summation order.  counters: host pointer, optional (forces a stream sync). */
+ * beyond floating-point summation order.  counters: host pointer, optional (forces a stream sync).
+ * A scene owns ONE render workspace (slice partials, queue cursors, counter block, profiling events)
+ * shared by pt_render_accumulate and pt_trace_rays: at most one such call per scene may be in flight;
+ * calls on the same stream serialise by themselves, calls on different streams must be ordered by the
+ * caller (events), or use one scene object per stream. */
 int pt_render_accumulate(pt_scene *scene, const pt_camera *camera, uint32_t seed,
                          int sample_begin, int sample_end, int n_split, float *d_split,
                          pt_counters *counters, void *stream);

@@ -224,6 +224,27 @@ class OracleScene:
         return a, s, sm, nn
 
 
+def scene_from_description(desc):
+    """Feeds a plain-array scene description (the dict the product's scene builders return: materials,
+    entities, hdri, camera) to the oracle; returns (OracleScene, Camera)."""
+    sc = OracleScene()
+    for m in desc["materials"]:
+        mid = sc.add_material(m["albedo"], m["specular"], m["emission"], m["smoothness"], m["smooth_shading"])
+        for which, data in m["maps"].items():
+            sc.set_map(mid, which, data)
+    for e in desc["entities"]:
+        if e["kind"] == "mesh":
+            sc.add_mesh(e["positions"], e["tri"], e["material"], normals=e["normals"], uvs=e["uvs"], octree_depth=e["octree_depth"])
+        else:
+            sc.add_sphere(e["center"], e["radius"], e["material"])
+    if desc.get("hdri"):
+        hd = desc["hdri"]
+        sc.set_hdri(hd["rgb"], hd["exposure"], hd["contrast"], hd["rot"], hd["smooth"])
+    c = desc["camera"]
+    cam = make_camera(c["position"], c["direction"], c["res"], c["focal_length"], c["aperture"], c["focus_distance"])
+    return sc, cam
+
+
 def camera_rays(cam, seed, sample):
     out = np.zeros((cam.res_y * cam.res_x, 6), dtype=np.float32)
     lib().orc_camera_rays(C.byref(cam), seed, sample, out.ctypes.data)

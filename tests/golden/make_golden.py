@@ -28,7 +28,7 @@ def golden_rays(cam_desc, res, seed, sample):
 def main():
     # teapot (octree depth 6) + floor + light: primary rays of a 96x54 pinhole sweep, and one bounce generation
     desc = S.teapot_scene(res=(96, 54))
-    sc, cam = S.build_oracle_scene(desc, O)
+    sc, cam = O.scene_from_description(desc)
     rays = golden_rays(desc["camera"], (96, 54), 1337, 0)
     hits, log, cnt = sc.trace(rays, log_stride=48)
     # secondary rays: from every hit, a deterministic pseudo-random direction (covers negative directions / mirroring)
@@ -46,7 +46,7 @@ def main():
                         counters2=np.array([cnt2[k] for k in O.COUNTER_NAMES], dtype=np.int64))
     # cornell box (brute force + spheres)
     desc = S.cornellbox_scene(res=(64, 36))
-    sc, cam = S.build_oracle_scene(desc, O)
+    sc, cam = O.scene_from_description(desc)
     rays = golden_rays(desc["camera"], (64, 36), 1337, 3)
     hits, log, cnt = sc.trace(rays, log_stride=16)
     np.savez_compressed(os.path.join(HERE, "cornell_trace.npz"), rays=rays, entity=hits["entity"], triangle=hits["triangle"],

@@ -33,7 +33,7 @@ def _worker(rank, world, port, out_path):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     desc = S.cornellbox_scene(res=(32, 18))
-    sc, cam = S.build_oracle_scene(desc, O)
+    sc, cam = O.scene_from_description(desc)
 
     def render_fn(b, e):
         img, _ = sc.render(cam, 1337, b, e)
@@ -54,7 +54,7 @@ def test_two_rank_sharded_render_equals_single(tmp_path, oracle, scenes):
     out = str(tmp_path / "img.npy")
     mp.spawn(_worker, args=(2, port, out), nprocs=2, join=True)
     got = np.load(out)
-    sc, cam = scenes.build_oracle_scene(scenes.cornellbox_scene(res=(32, 18)), oracle)
+    sc, cam = oracle.scene_from_description(scenes.cornellbox_scene(res=(32, 18)))
     want, _ = sc.render(cam, 1337, 0, 8)
     assert got.shape == want.shape
     # identical sample set; only the association of the final sums differs

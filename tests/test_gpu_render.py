@@ -22,7 +22,7 @@ def _rmse(a, b):
 
 def _pair(pt, oracle, scenes, desc):
     g, cam_g = pt.scene_from_description(desc)
-    c, cam_c = scenes.build_oracle_scene(desc, oracle)
+    c, cam_c = oracle.scene_from_description(desc)
     return g, cam_g, c, cam_c
 
 

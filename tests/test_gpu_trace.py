@@ -44,7 +44,7 @@ def _random_rays(rng, n, center, radius):
 def teapot_pair(pt, oracle, scenes):
     desc = scenes.teapot_scene(res=(96, 54))
     g, _ = pt.scene_from_description(desc)
-    c, _ = scenes.build_oracle_scene(desc, oracle)
+    c, _ = oracle.scene_from_description(desc)
     return g, c, desc
 
 

@@ -83,7 +83,7 @@ def test_octree_equals_brute_force_on_primary_rays(oracle, teapot):
 def test_golden_trace_vectors(oracle, scenes):
     for name, builder, res in (("teapot_trace.npz", scenes.teapot_scene, (96, 54)), ("cornell_trace.npz", scenes.cornellbox_scene, (64, 36))):
         g = np.load(os.path.join(GOLDEN, name))
-        sc, _ = scenes.build_oracle_scene(builder(res=res), oracle)
+        sc, _ = oracle.scene_from_description(builder(res=res))
         for sfx in ("", "2"):
             if "rays" + sfx not in g:
                 continue
@@ -141,7 +141,7 @@ def test_sphere_and_miss(oracle):
 
 def test_render_is_deterministic_and_additive(oracle, scenes):
     desc = scenes.cornellbox_scene(res=(32, 18))
-    sc, cam = scenes.build_oracle_scene(desc, oracle)
+    sc, cam = oracle.scene_from_description(desc)
     a, ca = sc.render(cam, 1337, 0, 4, n_threads=1)
     b, cb = sc.render(cam, 1337, 0, 4, n_threads=4)
     assert np.array_equal(a, b) and ca == cb

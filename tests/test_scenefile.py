@@ -107,10 +107,10 @@ def test_scene_file_feeds_the_oracle(tmp_path, scenes, oracle):
     path = tmp_path / "teapot.json"
     path.write_text(json.dumps(_teapot_doc(tmp_path, res=(32, 18))))
     desc, _ = sf.load_scene(str(path))
-    sc, cam = scenes.build_oracle_scene(desc, oracle)
+    sc, cam = oracle.scene_from_description(desc)
     rays = oracle.camera_rays(cam, 1337, 0)
     hits, _, _ = sc.trace(rays)
-    sc2, cam2 = scenes.build_oracle_scene(scenes.teapot_scene(res=(32, 18)), oracle)
+    sc2, cam2 = oracle.scene_from_description(scenes.teapot_scene(res=(32, 18)))
     hits2, _, _ = sc2.trace(oracle.camera_rays(cam2, 1337, 0))
     assert np.array_equal(hits["triangle"], hits2["triangle"]) and np.array_equal(hits["t"], hits2["t"])
     assert (hits["entity"] >= 0).sum() > 50
