@@ -9,6 +9,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <memory>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -78,6 +79,7 @@ struct pt_scene {
     uint32_t *d_tickets = nullptr;      /* kMaxQueues work-queue cursors */
     unsigned long long *d_stats = nullptr;
     bool stats_valid = false;           /* d_stats holds the scheduling counters of a counted render launch */
+    unsigned char *scratch = nullptr;   /* this device's copy of the fixed scratch array (pt_render_accumulate_noalloc) */
 
     bool profiling = false;             /* bracket the render kernel with HIP events */
     hipEvent_t ev_start = nullptr, ev_stop = nullptr;
@@ -87,6 +89,39 @@ struct pt_scene {
 namespace {
 
 constexpr int kMaxQueues = 4096;     /* upper bound on the persistent grid (workgroups) */
+
+/*
+ * Scratch of pt_render_accumulate_noalloc: the work-queue cursors and the slice partials of the render
+ * kernel, which pt_render_accumulate keeps in hipMalloc'ed workspace.  One copy of the array lives on
+ * every GPU the library is loaded on, from module load to process end.  Host code never passes the
+ * array's name to a kernel: the per-device address is resolved once with hipGetSymbolAddress
+ * (scratch_address) and only that pointer is used for kernel arguments and memsets.
+ */
+constexpr size_t kScratchTicketBytes = 64 * 1024;                       /* (kMaxQueues + 1) cursors, padded */
+constexpr size_t kScratchBytes = PT_NOALLOC_SCRATCH_BYTES;
+static_assert((kMaxQueues + 1) * sizeof(uint32_t) <= kScratchTicketBytes, "cursor area too small");
+static __device__ __align__(256) __attribute__((used)) unsigned char scratch[kScratchBytes];
+
+constexpr int kMaxDevices = 64;
+std::mutex g_scratch_mutex;
+unsigned char *g_scratch_ptr[kMaxDevices];      /* per device: address of that GPU's copy of `scratch` */
+
+/* address of device `dev`'s copy of the scratch array (resolved on first use, with that device current) */
+int scratch_address(int dev, unsigned char **out) {
+    if (dev < 0 || dev >= kMaxDevices) PT_FAIL("scratch_address: device index out of range");
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if (!g_scratch_ptr[dev]) {
+        int cur = -1;
+        PT_HIP(hipGetDevice(&cur));
+        if (cur != dev) PT_FAIL("scratch_address: device not current");
+        void *p = nullptr;
+        PT_HIP(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+        if (!p) PT_FAIL("scratch_address: hipGetSymbolAddress returned null");
+        g_scratch_ptr[dev] = static_cast<unsigned char *>(p);
+    }
+    *out = g_scratch_ptr[dev];
+    return 0;
+}
 
 struct DeviceGuard {
     int prev = -1;
@@ -450,6 +485,7 @@ int pt_scene_commit(pt_scene *scene) {
     PT_HIP(hipMalloc((void **)&scene->d_tickets, (kMaxQueues + 1) * sizeof(uint32_t)));
     PT_HIP(hipMalloc((void **)&scene->d_stats, 16 * sizeof(unsigned long long)));
     PT_HIP(hipMemset(scene->d_stats, 0, 16 * sizeof(unsigned long long)));
+    if (scratch_address(scene->device, &scene->scratch)) return 1;
     scene->committed = true;
     return 0;
 }
@@ -573,10 +609,10 @@ int pt_camera_rays(int device, const pt_camera *camera, uint32_t seed, int sampl
 
 namespace {
 
-/* fills everything of the launch parameters that follows from the camera and the sample range, and
- * makes the workspace large enough */
-int prepare_render(pt_scene *scene, const pt_camera *camera, uint32_t seed, int sample_begin, int sample_end, int n_split,
-                   hipStream_t stream, RenderParams &p) {
+/* fills everything of the launch parameters that follows from the camera and the sample range; returns the bytes of
+ * slice partials the launch needs in *need */
+int plan_render(pt_scene *scene, const pt_camera *camera, uint32_t seed, int sample_begin, int sample_end, int n_split,
+                RenderParams &p, size_t *need) {
     memset(&p, 0, sizeof p);
     p.sc = scene->dev;
     p.cam = *camera;
@@ -591,20 +627,22 @@ int prepare_render(pt_scene *scene, const pt_camera *camera, uint32_t seed, int 
     if (n_items >= 0xFFFF0000ull) PT_FAIL("pt_render_accumulate: too many work items");
     p.n_items = (uint32_t)n_items;
     const int64_t n_pixels = (int64_t)camera->res_x * camera->res_y;
-    const size_t need = (size_t)n_slices * (size_t)n_pixels * 12;
-    if (scene->partials.bytes < need) {
-        /* the previous launch may still read the old workspace */
-        PT_HIP(hipStreamSynchronize(stream));
-        if (scene->partials.p) PT_HIP(hipFree(scene->partials.p));
-        scene->partials = DevBuf();
-        PT_HIP(hipMalloc(&scene->partials.p, need));
-        scene->partials.bytes = need;
-    }
-    p.partials = (float *)scene->partials.p;
-    p.tickets = scene->d_tickets;
+    *need = (size_t)n_slices * (size_t)n_pixels * 12;
     p.stats = nullptr;
     p.done_quota = scene->quorum;
     p.leaf_quota = scene->leaf_quota;
+    return 0;
+}
+
+int check_render_args(const char *who, pt_scene *scene, const pt_camera *camera, int sample_begin, int sample_end, int n_split,
+                      float *d_split) {
+    const std::string w(who);
+    if (!scene || !camera || !d_split) PT_FAIL(w + ": null argument");
+    if (!scene->committed) PT_FAIL(w + ": scene not committed");
+    if (camera->res_x <= 0 || camera->res_y <= 0) PT_FAIL(w + ": empty image");
+    if (sample_begin < 0 || sample_end < sample_begin) PT_FAIL(w + ": bad sample range");
+    if (n_split < 1 || n_split > 64) PT_FAIL(w + ": n_split must be in [1,64]");
+    if (!is_device_pointer(d_split)) PT_FAIL(w + ": d_split must be a device pointer");
     return 0;
 }
 
@@ -620,12 +658,7 @@ int ensure_events(pt_scene *scene) {
 
 int pt_render_accumulate(pt_scene *scene, const pt_camera *camera, uint32_t seed, int sample_begin, int sample_end,
                          int n_split, float *d_split, pt_counters *counters, void *stream_) {
-    if (!scene || !camera || !d_split) PT_FAIL("pt_render_accumulate: null argument");
-    if (!scene->committed) PT_FAIL("pt_render_accumulate: scene not committed");
-    if (camera->res_x <= 0 || camera->res_y <= 0) PT_FAIL("pt_render_accumulate: empty image");
-    if (sample_begin < 0 || sample_end < sample_begin) PT_FAIL("pt_render_accumulate: bad sample range");
-    if (n_split < 1 || n_split > 64) PT_FAIL("pt_render_accumulate: n_split must be in [1,64]");
-    if (!is_device_pointer(d_split)) PT_FAIL("pt_render_accumulate: d_split must be a device pointer");
+    if (check_render_args("pt_render_accumulate", scene, camera, sample_begin, sample_end, n_split, d_split)) return 1;
     if (sample_end == sample_begin) {
         if (counters) memset(counters, 0, sizeof *counters);
         return 0;
@@ -635,7 +668,18 @@ int pt_render_accumulate(pt_scene *scene, const pt_camera *camera, uint32_t seed
     hipStream_t stream = (hipStream_t)stream_;
     const int64_t n_pixels = (int64_t)camera->res_x * camera->res_y;
     RenderParams p;
-    if (prepare_render(scene, camera, seed, sample_begin, sample_end, n_split, stream, p)) return 1;
+    size_t need = 0;
+    if (plan_render(scene, camera, seed, sample_begin, sample_end, n_split, p, &need)) return 1;
+    if (scene->partials.bytes < need) {
+        /* the previous launch may still read the old workspace */
+        PT_HIP(hipStreamSynchronize(stream));
+        if (scene->partials.p) PT_HIP(hipFree(scene->partials.p));
+        scene->partials = DevBuf();
+        PT_HIP(hipMalloc(&scene->partials.p, need));
+        scene->partials.bytes = need;
+    }
+    p.partials = (float *)scene->partials.p;
+    p.tickets = scene->d_tickets;
     p.stats = counters ? scene->d_stats : nullptr;
     PT_HIP(hipMemsetAsync(scene->d_tickets, 0, (kMaxQueues + 1) * sizeof(uint32_t), stream));
     if (counters) PT_HIP(hipMemsetAsync(scene->d_stats, 0, 16 * sizeof(unsigned long long), stream));
@@ -656,6 +700,39 @@ int pt_render_accumulate(pt_scene *scene, const pt_camera *camera, uint32_t seed
         counters_from(h, counters);
         scene->stats_valid = true;
     }
+    return 0;
+}
+
+size_t pt_noalloc_max_partial_bytes(void) { return kScratchBytes - kScratchTicketBytes; }
+
+int pt_render_accumulate_noalloc(pt_scene *scene, const pt_camera *camera, uint32_t seed, int sample_begin, int sample_end,
+                                 int n_split, float *d_split, void *stream_) {
+    if (check_render_args("pt_render_accumulate_noalloc", scene, camera, sample_begin, sample_end, n_split, d_split)) return 1;
+    if (sample_end == sample_begin) return 0;
+    DeviceGuard g(scene->device);
+    if (!g.ok) PT_FAIL("pt_render_accumulate_noalloc: cannot select device");
+    hipStream_t stream = (hipStream_t)stream_;
+    const int64_t n_pixels = (int64_t)camera->res_x * camera->res_y;
+    RenderParams p;
+    size_t need = 0;
+    if (plan_render(scene, camera, seed, sample_begin, sample_end, n_split, p, &need)) return 1;
+    if (need > kScratchBytes - kScratchTicketBytes) {
+        char buf[256];
+        snprintf(buf, sizeof buf,
+                 "pt_render_accumulate_noalloc: %zu bytes of slice partials (%d slices x %lld pixels x 12) exceed the fixed scratch of %zu bytes: "
+                 "render fewer samples or a smaller frame per call",
+                 need, p.plan.n_split * p.plan.slices_per_split, (long long)n_pixels, kScratchBytes - kScratchTicketBytes);
+        PT_FAIL(buf);
+    }
+    unsigned char *base = scene->scratch;        /* this device's copy of the scratch array, resolved at commit */
+    if (!base) PT_FAIL("pt_render_accumulate_noalloc: scratch address not resolved");
+    p.tickets = reinterpret_cast<uint32_t *>(base);
+    p.partials = reinterpret_cast<float *>(base + kScratchTicketBytes);
+    /* the array keeps the previous call's contents: the cursors must start at zero; every partial the
+     * compounding kernel reads is written by the render kernel first */
+    PT_HIP(hipMemsetAsync(p.tickets, 0, (kMaxQueues + 1) * sizeof(uint32_t), stream));
+    if (launch_render(p, scene->n_cu, kMaxQueues, scene->heavy, stream)) return 1;
+    if (launch_compound_partials(p.partials, d_split, n_pixels, p.plan, stream)) return 1;
     return 0;
 }
 

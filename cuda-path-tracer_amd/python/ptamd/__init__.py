@@ -57,7 +57,7 @@ ABI_SYMBOLS = [
     "pt_last_error", "pt_device_count", "pt_device_name", "pt_scene_create", "pt_scene_destroy", "pt_scene_add_material",
     "pt_scene_add_mesh", "pt_scene_add_sphere", "pt_scene_set_hdri", "pt_scene_commit", "pt_scene_octree_info",
     "pt_scene_octree_dump", "pt_scene_device_bytes", "pt_trace_rays", "pt_camera_rays", "pt_render_accumulate",
-    "pt_scene_set_launch", "pt_scene_get_launch",
+    "pt_render_accumulate_noalloc", "pt_noalloc_max_partial_bytes", "pt_scene_set_launch", "pt_scene_get_launch",
     "pt_scene_set_profiling", "pt_scene_schedule_counters", "pt_scene_last_render_kernel_ms", "pt_compound_buffers", "pt_apply_filter", "pt_make_gaussian", "pt_make_mean", "pt_normalize_image", "pt_apply_threshold",
     "pt_image_add", "pt_apply_aces", "pt_gamma_correct", "pt_post_chain", "pt_malloc", "pt_free", "pt_memset", "pt_upload",
     "pt_download", "pt_stream_synchronize",
@@ -90,6 +90,9 @@ def lib():
         L.pt_trace_rays.argtypes = [vp, vp, i64, vp, vp, i32, vp, vp]
         L.pt_camera_rays.argtypes = [i32, C.POINTER(Camera), u32, i32, vp, vp]
         L.pt_render_accumulate.argtypes = [vp, C.POINTER(Camera), u32, i32, i32, i32, vp, vp, vp]
+        L.pt_render_accumulate_noalloc.argtypes = [vp, C.POINTER(Camera), u32, i32, i32, i32, vp, vp]
+        L.pt_noalloc_max_partial_bytes.argtypes = []
+        L.pt_noalloc_max_partial_bytes.restype = C.c_size_t
         L.pt_scene_set_launch.argtypes = [vp, i32, i32]
         L.pt_scene_get_launch.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]
         L.pt_scene_set_profiling.argtypes = [vp, i32]
@@ -276,6 +279,10 @@ class Scene:
         check(self.L.pt_render_accumulate(self.h, C.byref(cam), seed, sample_begin, sample_end, n_split, d_split_ptr,
                                           C.byref(cnt) if want_counters else None, stream))
         return cnt.as_dict() if want_counters else None
+
+    def render_accumulate_noalloc(self, cam, seed, sample_begin, sample_end, n_split, d_split_ptr, stream=None):
+        """pt_render_accumulate without any allocation (fixed scratch array; see include/ptamd.h for its size limit)."""
+        check(self.L.pt_render_accumulate_noalloc(self.h, C.byref(cam), seed, sample_begin, sample_end, n_split, d_split_ptr, stream))
 
     def set_launch(self, kernel_build=None, quorum=None):
         """Fixes the kernel build ("heavy" / "light") and / or the quorum (1..64); None leaves a choice as it is."""

@@ -156,6 +156,23 @@ int pt_camera_rays(int device, const pt_camera *camera, uint32_t seed, int sampl
 int pt_render_accumulate(pt_scene *scene, const pt_camera *camera, uint32_t seed,
                          int sample_begin, int sample_end, int n_split, float *d_split,
                          pt_counters *counters, void *stream);
+/* Variant of pt_render_accumulate that allocates nothing.  It has no counterpart in the reference; it is
+ * for callers that cannot call hipMalloc: code under HIP graph capture, tight serving loops, harnesses
+ * that forbid allocation.  Same arguments, same kernels and the same image bits as pt_render_accumulate
+ * (without counters), but the render kernel's work-queue cursors and slice partials live in a fixed
+ * array of PT_NOALLOC_SCRATCH_BYTES in the library's device image instead of a workspace grown with
+ * hipMalloc; every GPU the library runs on holds that array until the process ends.  A launch needs
+ * slices x W x H x 12 bytes of partials, where slices = n_split x min(64 / n_split,
+ * ceil(ceil(samples / n_split) / 8)); the call fails with a clear error when that exceeds
+ * pt_noalloc_max_partial_bytes() (e.g. 1920x1080: two slices = up to 16 samples per call with n_split 1;
+ * 640x360: 24 slices).  All calls on one GPU share the array, whatever their scene or stream: calls
+ * that overlap in time on one GPU race and produce wrong images -- serialise them (one stream, or
+ * events). */
+#define PT_NOALLOC_SCRATCH_BYTES (64u << 20)
+int pt_render_accumulate_noalloc(pt_scene *scene, const pt_camera *camera, uint32_t seed,
+                                 int sample_begin, int sample_end, int n_split, float *d_split,
+                                 void *stream);
+size_t pt_noalloc_max_partial_bytes(void);
 /* Launch choices (no counterpart in the reference).  The render kernel has two launch choices that
  * change how a wave schedules its lanes and nothing a path computes (images are bit-identical under
  * all of them): the kernel build (0 = light: 4 waves per SIMD, every lane tests the triangle runs of
