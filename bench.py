@@ -12,11 +12,17 @@ work is fixed: strong scaling.  The scene (procedural stand-ins for the referenc
 80k.obj, textures and HDRI) is resident in HBM before the timed region starts; scene generation,
 octree build, upload and post-processing are reported separately and are not part of `value`.
 
+`--gpus N` without a launcher (no WORLD_SIZE in the environment) starts the N ranks itself as child
+processes.  `--backend gloo` (or PTAMD_DIST_BACKEND=gloo) runs the collective over gloo on host
+copies and lets several ranks share one GPU: a rehearsal of the N > 1 path on a one-GPU box.
+
 Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -34,6 +40,46 @@ B_ENTITY = 128               # entity record + AABB per (segment, entity)
 
 
 VALU_PEAK_TFLOPS = 157.3       # fp32 vector peak of one MI355X (256 CUs x 128 lanes x 2 flop x 2.4 GHz)
+N_SIMD = 1024                  # 256 CUs x 4 SIMDs
+NOMINAL_GHZ = 2.4
+# lane-operations per second when every SIMD keeps its vector unit busy with all 64 lanes of each instruction
+# active, at the one-instruction-per-four-cycles rate the PMC busy time is counted in
+LANE_OP_PEAK_T = N_SIMD * 16 * NOMINAL_GHZ / 1e3       # = 39.3 T lane-op/s
+
+
+def launch_ranks(n):
+    """Starts ranks 0..n-1 of this script as child processes (before this process touches a GPU) and
+    returns the worst exit code."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    for p in procs:
+        rc = max(rc, abs(p.wait()))
+    return rc
+
+
+def stamped_profile(name, workload_name, world):
+    """Counter results of separate rocprofv3 --pmc passes over this benchmark (profiles/run_profile.sh +
+    profiles/collect.py write them).  They are only reported when they were measured on this very workload
+    with the library sources as they are now (SHA-256 of csrc/ + the header): otherwise None."""
+    import ptamd
+
+    if world != 1:
+        return None
+    try:
+        with open(os.path.join(REPO, "profiles", "r2", name)) as f:
+            d = json.load(f)
+    except (OSError, ValueError):
+        return None
+    if d.get("workload") != workload_name or not d.get("source_hash") or d.get("source_hash") != ptamd.source_hash():
+        return None
+    return d
 
 
 def algorithmic_flops(counters, n_mesh_entities):
@@ -41,13 +87,6 @@ def algorithmic_flops(counters, n_mesh_entities):
     for every mesh entity and about 150 of shading."""
     return (counters["tri_tests"] * 50 + counters["node_visits"] * 25
             + counters["segments"] * (24 * n_mesh_entities + 150))
-
-
-def algorithmic_bytes(counters, n_pixels, n_slices, n_entities):
-    hits = counters["segments"] - counters["env_lookups"] if counters["env_lookups"] else counters["segments"]
-    return (counters["node_visits"] * B_NODE + counters["tri_tests"] * B_TRI + hits * B_SHADE
-            + counters["tex_fetches"] * B_TEXEL + counters["env_lookups"] * B_ENV
-            + counters["segments"] * n_entities * B_ENTITY + n_pixels * 12 * n_slices)
 
 
 def main():
@@ -60,7 +99,14 @@ def main():
     ap.add_argument("--res", type=str, default="", help="override resolution WxH")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--save-ppm", type=str, default="", help="write the post-processed image of the last step")
+    ap.add_argument("--backend", default=os.environ.get("PTAMD_DIST_BACKEND", "nccl"), choices=["nccl", "gloo"],
+                    help="collective backend for N > 1 (nccl = RCCL; gloo: host copies, ranks may share a GPU)")
     args = ap.parse_args()
+    if args.gpus < 1:
+        ap.error("--gpus must be at least 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # no launcher: run the ranks as children of this process (which has not initialised any GPU)
+        sys.exit(launch_ranks(args.gpus))
 
     import numpy as np
     import torch
@@ -73,15 +119,22 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with python -m torch.distributed.run "
+                         f"--nproc-per-node {args.gpus} bench.py --gpus {args.gpus} ..., or without a launcher")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
+    n_dev = torch.cuda.device_count()
+    if args.backend == "nccl" and world > n_dev:
+        raise SystemExit(f"{world} ranks but {n_dev} GPU(s): RCCL needs one GPU per rank (use --backend gloo to rehearse on fewer)")
+    dev = local_rank % n_dev
+    torch.cuda.set_device(dev)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-    dev = local_rank
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev))
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
 
     cfg = S.CONFIGS[args.workload]
     res = tuple(int(x) for x in args.res.split("x")) if args.res else cfg["res"]
@@ -107,7 +160,13 @@ def main():
         cnt = scene.render_accumulate(cam, 1337, s_begin, s_end, n_split, split.data_ptr(), want_counters, stream)
         ptamd.check(L.pt_compound_buffers(dev, split.data_ptr(), local_sum.data_ptr(), n_pixels, n_split, stream))
         if world > 1:
-            dist.reduce(local_sum, dst=0, op=dist.ReduceOp.SUM)
+            if args.backend == "nccl":
+                dist.reduce(local_sum, dst=0, op=dist.ReduceOp.SUM)
+            else:
+                host = local_sum.cpu()
+                dist.reduce(host, dst=0, op=dist.ReduceOp.SUM)
+                if rank == 0:
+                    local_sum.copy_(host)
         return cnt
 
     def fence():
@@ -134,8 +193,9 @@ def main():
     elapsed = time.perf_counter() - t0
     scene.set_profiling(False)
 
-    t = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{dev}")
-    cvec = torch.tensor([counters[k] for k in ptamd.COUNTER_NAMES], dtype=torch.float64, device=f"cuda:{dev}")
+    cdev = f"cuda:{dev}" if args.backend == "nccl" else "cpu"
+    t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
+    cvec = torch.tensor([counters[k] for k in ptamd.COUNTER_NAMES], dtype=torch.float64, device=cdev)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dist.all_reduce(cvec, op=dist.ReduceOp.SUM)
@@ -146,41 +206,55 @@ def main():
     paths_per_step = n_pixels * spp
     value = paths_per_step / (ms_per_step / 1000.0) / 1e6
 
-    # roofline of the dominant kernel (this rank's launch): algorithmic bytes / measured kernel time
+    # ---- roofline of the dominant kernel (this rank's launch of render_kernel)
     plan_slices = n_split * min(max(1, 64 // n_split), max(1, (-(-(s_end - s_begin) // n_split) + 7) // 8))   # make_slice_plan
     k_ms = float(np.mean(kernel_ms)) if kernel_ms else float("nan")
-    alg_bytes = algorithmic_bytes(counters, n_pixels, plan_slices, n_entities)
-    achieved = alg_bytes / (k_ms / 1000.0) / 1e9 if k_ms > 0 else 0.0
-    # memory-side bytes per launch come from a PMC pass (rocprofv3 cannot run inside this process): the committed
-    # measurement of this exact workload is reported when there is one, otherwise null
-    traffic, traffic_source = None, None
-    workload_name = f"{args.workload} {res[0]}x{res[1]} {spp}spp octree-depth-{max(e.get('octree_depth', 0) for e in desc['entities'] if e['kind'] == 'mesh')}"
-    try:
-        with open(os.path.join(REPO, "profiles", "r1", "traffic.json")) as f:
-            tj = json.load(f)
-        if tj.get("workload") == workload_name and world == 1:
-            traffic, traffic_source = int(tj["traffic_bytes_per_launch"]), "profiles/r1/traffic.json"
-    except (OSError, ValueError, KeyError):
-        pass
-    # the second ceiling: useful fp32 operations against the vector peak (low by construction: the kernel saturates
-    # instruction issue with 37 % of the lanes active, and most instructions are compares, selects and address work)
+    k_s = k_ms / 1000.0
+    workload_name = f"{args.workload} {res[0]}x{res[1]} {spp}spp octree-depth-{max([e.get('octree_depth', 0) for e in desc['entities'] if e['kind'] == 'mesh'] or [0])}"
+    # (a) demand on the scene arrays, by array: counters of this launch x bytes one unit of work needs.  These
+    # are requests to the cache hierarchy (the geometry working set is L1 / L2 resident), not HBM traffic.
+    hits = counters["segments"] - counters["env_lookups"] if counters["env_lookups"] else counters["segments"]
+    demand = {"nodes": counters["node_visits"] * B_NODE, "triangles": counters["tri_tests"] * B_TRI, "shade_records": hits * B_SHADE,
+              "texels": counters["tex_fetches"] * B_TEXEL, "hdri": counters["env_lookups"] * B_ENV,
+              "entities": counters["segments"] * n_entities * B_ENTITY, "partials": n_pixels * 12 * plan_slices}
+    alg_bytes = int(sum(demand.values()))
+    fetch_demand = {k: round(v / k_s / 1e9, 1) for k, v in demand.items()} if k_ms > 0 else None
+    # (b) compulsory HBM bytes of one launch: every scene array once, every slice partial written once
+    sbytes = scene.device_bytes()
+    partial_bytes = n_pixels * 12 * plan_slices
+    compulsory = int(sum(sbytes.values()) + partial_bytes)
+    # (c) measured memory-side traffic and VALU occupancy: separate rocprofv3 --pmc passes (they cannot run inside
+    # this process), reported only when stamped with this workload and the current library sources
+    tj = stamped_profile("traffic.json", workload_name, world)
+    pj = stamped_profile("pmc_ratios.json", workload_name, world)
+    traffic = fetch_b = write_b = None
+    if tj:
+        fetch_b, write_b = int(tj["FETCH_SIZE_KB"] * 1024 * 2), int(tj["WRITE_SIZE_KB"] * 1024)      # gfx950: FETCH_SIZE counts half
+        traffic = fetch_b + write_b
+    hbm = {"peak_GBps": HBM_PEAK_GBPS, "compulsory_bytes_per_launch": compulsory,
+           "compulsory_frac": round(compulsory / k_s / 1e9 / HBM_PEAK_GBPS, 6) if k_ms > 0 else None,
+           "fetch_bytes_per_launch": fetch_b, "write_bytes_per_launch": write_b,
+           "traffic_frac": round(traffic / k_s / 1e9 / HBM_PEAK_GBPS, 4) if traffic and k_ms > 0 else None,
+           "write_amplification": round(write_b / partial_bytes, 2) if write_b else None,
+           "traffic_source": "profiles/r2/traffic.json" if tj else None}
+    # (d) what binds: vector-instruction issue.  frac = (share of the time the SIMDs' vector units are busy) x (mean share
+    # of the 64 lanes active in a vector instruction) = share of the chip's lane slots that do work
     n_mesh = sum(1 for e in desc["entities"] if e["kind"] == "mesh")
     alg_flops = algorithmic_flops(counters, n_mesh)
-    tflops = alg_flops / (k_ms / 1000.0) / 1e12 if k_ms > 0 else 0.0
-    valu_roofline = {"achieved": round(tflops, 3), "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tflops / VALU_PEAK_TFLOPS, 5),
-                     "algorithmic_flops_per_launch": int(alg_flops)}
-    # VALU utilisation and cache rates of the same workload, from the committed counter passes (same rule as traffic)
-    pmc = None
-    try:
-        with open(os.path.join(REPO, "profiles", "r1", "pmc_ratios.json")) as f:
-            pj = json.load(f)
-        if pj.get("workload") == workload_name and world == 1:
-            pmc = {k: v for k, v in pj.items() if k not in ("workload",)}
-    except (OSError, ValueError):
-        pass
-    roofline = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic, "traffic_source": traffic_source,
-                "kernel": "render_kernel", "kernel_ms": round(k_ms, 3), "algorithmic_bytes_per_launch": int(alg_bytes)}
+    tflops = alg_flops / k_s / 1e12 if k_ms > 0 else 0.0
+    busy = pj.get("valu_busy") if pj else None
+    lanes = pj.get("active_lanes_per_valu_instruction") if pj else None
+    frac = round(min(busy, 1.0) * lanes, 4) if busy is not None and lanes is not None else None
+    roofline = {"bound": "valu-issue", "achieved": round(frac * LANE_OP_PEAK_T, 2) if frac is not None else None,
+                "peak": round(LANE_OP_PEAK_T, 2), "unit": "Tlane-op/s", "frac": frac,
+                "valu_busy": busy, "active_lane_fraction": lanes, "pmc_source": "profiles/r2/pmc_ratios.json" if pj else None,
+                "traffic": traffic, "kernel": "render_kernel", "kernel_ms": round(k_ms, 3),
+                "hbm": hbm,
+                "cache_demand": {"bytes_per_launch": alg_bytes, "GBps": round(alg_bytes / k_s / 1e9, 1) if k_ms > 0 else None,
+                                 "GBps_by_array": fetch_demand},
+                "useful_fp32": {"TFLOPs": round(tflops, 3), "frac_of_vector_peak": round(tflops / VALU_PEAK_TFLOPS, 5),
+                                "flops_per_launch": int(alg_flops)}}
+    pmc = {k: v for k, v in pj.items() if k not in ("workload", "source_hash")} if pj else None
 
     cpu_baseline = None
     parity = None
@@ -217,8 +291,9 @@ def main():
             img_g, gcnt = ptamd.render_image(scene, cam, n_cpu, seed=1337, sample_begin=1, device=dev, want_counters=True)
             diff = (img_g.astype(np.float64) - img_c.astype(np.float64)) / n_cpu
             rms = float(np.sqrt(np.mean((img_c.astype(np.float64) / n_cpu) ** 2)))
+            ref_px = np.abs(img_c.astype(np.float64) / n_cpu).max(axis=-1)
             parity = {"rmse_over_rms": round(float(np.sqrt(np.mean(diff ** 2))) / max(rms, 1e-30), 6), "spp": n_cpu,
-                      "pixels_differing": int((np.abs(diff).max(axis=-1) > 1e-4 * rms).sum()), "pixels": n_pixels,
+                      "pixels_differing": int((np.abs(diff).max(axis=-1) > 2e-4 * (rms + ref_px)).sum()), "pixels": n_pixels,
                       "counters_rel_diff": {k: round(abs(gcnt[k] - ccnt[k]) / max(ccnt[k], 1), 7)
                                             for k in ("paths", "segments", "node_visits", "tri_tests", "env_lookups", "tex_fetches")}}
             cpu_baseline = {"value": round(n_pixels * n_cpu / tn / 1e6, 4), "unit": "Mpaths/s", "cores": cores, "kind": "port",
@@ -236,10 +311,10 @@ def main():
             "time_to_spp_s": round(ms_per_step / 1000.0, 4),
             "msegments_per_s": round(total_counters["segments"] / (ms_per_step / 1000.0) / 1e6, 2),
             "counters": total_counters, "schedule": schedule, "launch": launch,
-            "roofline": roofline, "valu_roofline": valu_roofline, "pmc": pmc, "cpu_baseline": cpu_baseline, "parity_vs_oracle": parity,
+            "roofline": roofline, "pmc": pmc, "cpu_baseline": cpu_baseline, "parity_vs_oracle": parity,
             "post_chain_ms": None if post_ms is None else round(post_ms, 2),
             "scene_gen_s": round(t_gen, 2), "scene_build_upload_s": round(t_upload, 2),
-            "scene_device_bytes": scene.device_bytes(),
+            "scene_device_bytes": sbytes, "library_source_hash": ptamd.source_hash(), "backend": args.backend if world > 1 else None,
         }
         print(json.dumps(line), flush=True)
     if world > 1:

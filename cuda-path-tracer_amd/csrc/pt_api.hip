@@ -201,6 +201,24 @@ uint32_t append_run(std::vector<PtTriPair> &pairs, const float *pos, const int32
     return first * (uint32_t)(sizeof(PtTriPair) / 16);
 }
 
+/* runs launch(d_in, d_out) on device copies of a host input of in_bytes and downloads out_bytes of results */
+template <typename F>
+int staged_query(size_t in_bytes, const void *h_in, size_t out_bytes, void *h_out, F launch) {
+    void *d_in = nullptr, *d_out = nullptr;
+    int rc = 0;
+    do {
+        if (hipMalloc(&d_in, in_bytes) != hipSuccess || hipMalloc(&d_out, out_bytes) != hipSuccess) { rc = 1; set_error("query: out of device memory"); break; }
+        if (hipMemcpy(d_in, h_in, in_bytes, hipMemcpyHostToDevice) != hipSuccess) { rc = 1; set_error("query: upload failed"); break; }
+        rc = launch(d_in, d_out);
+        if (rc) break;
+        hipError_t e = hipMemcpy(h_out, d_out, out_bytes, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) { rc = hip_fail(e, "hipMemcpy", __FILE__, __LINE__); break; }
+    } while (0);
+    if (d_in) (void)hipFree(d_in);
+    if (d_out) (void)hipFree(d_out);
+    return rc;
+}
+
 void counters_from(const unsigned long long h[7], pt_counters *c) {
     c->segments = h[0]; c->aabb_tests = h[1]; c->node_visits = h[2]; c->tri_tests = h[3];
     c->env_lookups = h[4]; c->tex_fetches = h[5]; c->paths = h[6];
@@ -749,6 +767,63 @@ int pt_scene_get_launch(pt_scene *scene, int *kernel_build, int *quorum) {
     if (!scene) PT_FAIL("pt_scene_get_launch: null argument");
     if (kernel_build) *kernel_build = scene->heavy ? 1 : 0;
     if (quorum) *quorum = scene->quorum;
+    return 0;
+}
+
+int pt_sample_hdri(pt_scene *scene, const float *dirs, int64_t n, float *rgb_out) {
+    if (!scene) PT_FAIL("pt_sample_hdri: null scene");
+    if (!scene->committed) PT_FAIL("pt_sample_hdri: scene not committed");
+    if (n < 0) PT_FAIL("pt_sample_hdri: negative count");
+    if (n == 0) return 0;
+    if (!dirs || !rgb_out) PT_FAIL("pt_sample_hdri: null buffer");
+    DeviceGuard g(scene->device);
+    if (!g.ok) PT_FAIL("pt_sample_hdri: cannot select device");
+    return staged_query((size_t)n * 12, dirs, (size_t)n * 12, rgb_out, [&](void *d_in, void *d_out) {
+        return launch_sample_hdri(scene->dev, (const float *)d_in, n, (float *)d_out, nullptr);
+    });
+}
+
+int pt_sample_material(pt_scene *scene, int material, const float *uv, int64_t n, float *albedo, float *specular, float *smoothness,
+                       float *normal) {
+    if (!scene) PT_FAIL("pt_sample_material: null scene");
+    if (!scene->committed) PT_FAIL("pt_sample_material: scene not committed");
+    if (material < 0 || material >= (int)scene->materials.size()) PT_FAIL("pt_sample_material: unknown material");
+    if (n < 0) PT_FAIL("pt_sample_material: negative count");
+    if (n == 0) return 0;
+    if (!uv || !albedo || !specular || !smoothness || !normal) PT_FAIL("pt_sample_material: null buffer");
+    DeviceGuard g(scene->device);
+    if (!g.ok) PT_FAIL("pt_sample_material: cannot select device");
+    std::vector<float> packed((size_t)n * 10);
+    if (staged_query((size_t)n * 8, uv, packed.size() * sizeof(float), packed.data(), [&](void *d_in, void *d_out) {
+            return launch_sample_material(scene->dev, material, (const float *)d_in, n, (float *)d_out, nullptr);
+        }))
+        return 1;
+    for (int64_t i = 0; i < n; i++) {
+        const float *o = &packed[(size_t)i * 10];
+        memcpy(albedo + 3 * i, o, 12);
+        memcpy(specular + 3 * i, o + 3, 12);
+        smoothness[i] = o[6];
+        memcpy(normal + 3 * i, o + 7, 12);
+    }
+    return 0;
+}
+
+int pt_box_intersects_triangle(const float bmin[3], const float bmax[3], const float v0[3], const float v1[3], const float v2[3],
+                               int pad_box, int *overlaps) {
+    if (!bmin || !bmax || !v0 || !v1 || !v2 || !overlaps) PT_FAIL("pt_box_intersects_triangle: null argument");
+    float mn[3], mx[3];
+    for (int k = 0; k < 3; k++) {
+        mn[k] = pad_box ? bmin[k] - 0.0001f : bmin[k];      /* AABB_PADDING, src/geometry.cuh:7,81-84 */
+        mx[k] = pad_box ? bmax[k] + 0.0001f : bmax[k];
+    }
+    *overlaps = box_intersects_triangle(mn, mx, v0, v1, v2) ? 1 : 0;
+    return 0;
+}
+
+int pt_scene_render_residency(pt_scene *scene, int *workgroups_per_cu) {
+    if (!scene || !workgroups_per_cu) PT_FAIL("pt_scene_render_residency: null argument");
+    if (!scene->committed) PT_FAIL("pt_scene_render_residency: scene not committed");
+    *workgroups_per_cu = render_workgroups_per_cu(scene->dev.max_depth, scene->heavy);
     return 0;
 }
 

@@ -55,8 +55,11 @@ struct RenderParams {
 /* kernel launchers (pt_kernels.hip); all asynchronous on `stream` */
 int launch_trace(const PtSceneDev &sc, const float *d_rays, int64_t n, pt_hit *d_hits, int32_t *d_log,
                  int log_stride, unsigned long long *d_stats, hipStream_t stream);
+int launch_sample_hdri(const PtSceneDev &sc, const float *d_dirs, int64_t n, float *d_out, hipStream_t stream);
+int launch_sample_material(const PtSceneDev &sc, int material, const float *d_uv, int64_t n, float *d_out, hipStream_t stream);
 int launch_camera_rays(const pt_camera &cam, uint32_t seed, int sample, float *d_rays, hipStream_t stream);
 /* heavy: the build for scenes dominated by octree traversal (more waves per SIMD, fewer registers) */
+int render_workgroups_per_cu(int max_depth, bool heavy);
 int launch_render(RenderParams p, int n_cu, int max_queues, bool heavy, hipStream_t stream);
 int launch_compound_partials(const float *d_partials, float *d_split, int64_t n_pixels, const SlicePlan &plan,
                              hipStream_t stream);

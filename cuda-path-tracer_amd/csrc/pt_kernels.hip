@@ -309,6 +309,43 @@ __global__ void __launch_bounds__(kBlock) camera_rays_kernel(pt_camera cam, uint
     r[0] = o.x; r[1] = o.y; r[2] = o.z; r[3] = d.x; r[4] = d.y; r[5] = d.z;
 }
 
+/* ------------------------------------------------------------------ parity queries of the shading inputs */
+/* the environment lookup of the render kernel for caller-supplied directions */
+__global__ void __launch_bounds__(kBlock) sample_hdri_kernel(PtSceneDev sc, const float *__restrict__ dirs, int64_t n,
+                                                             float *__restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    Stats st;
+    const V3 c = sample_hdri<false>(sc, mk(dirs[3 * i], dirs[3 * i + 1], dirs[3 * i + 2]), st);
+    out[3 * i] = c.x; out[3 * i + 1] = c.y; out[3 * i + 2] = c.z;
+}
+
+/* the four material samples at the head of shade_hit for caller-supplied (u, v): out = n x 10 floats
+ * {albedo rgb, specular rgb, smoothness, tangent-space normal xyz} */
+__global__ void __launch_bounds__(kBlock) sample_material_kernel(PtSceneDev sc, int material, const float *__restrict__ uv,
+                                                                 int64_t n, float *__restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const PtMaterial &m = sc.materials[material];
+    const float u = uv[2 * i], v = uv[2 * i + 1];
+    V3 ts_normal = mk(0.f, 0.f, 1.f);
+    if (m.map[2]) {
+        const V3 c = tex_rgb(m.map[2], m.map_w[2], m.map_h[2], u, v);
+        ts_normal = fast_normalized(mk(2.0f * c.x - 1.0f, 2.0f * c.y - 1.0f, 2.0f * c.z - 1.0f));
+    }
+    V3 albedo = mk(m.albedo[0], m.albedo[1], m.albedo[2]);
+    if (m.map[0]) albedo = tex_rgb(m.map[0], m.map_w[0], m.map_h[0], u, v);
+    float smoothness = m.smoothness;
+    if (m.map[3]) smoothness = tex_gray(m.map[3], m.map_w[3], m.map_h[3], u, v);
+    V3 specular = mk(m.specular[0], m.specular[1], m.specular[2]);
+    if (m.map[1]) specular = tex_rgb(m.map[1], m.map_w[1], m.map_h[1], u, v);
+    float *o = out + 10 * i;
+    o[0] = albedo.x; o[1] = albedo.y; o[2] = albedo.z;
+    o[3] = specular.x; o[4] = specular.y; o[5] = specular.z;
+    o[6] = smoothness;
+    o[7] = ts_normal.x; o[8] = ts_normal.y; o[9] = ts_normal.z;
+}
+
 /* ------------------------------------------------------------------ persistent render kernel */
 __device__ __forceinline__ void slice_range(const SlicePlan &pl, int slice, int &s0, int &s1) {
     const int z = slice / pl.slices_per_split, j = slice - z * pl.slices_per_split;
@@ -555,6 +592,20 @@ int launch_trace(const PtSceneDev &sc, const float *d_rays, int64_t n, pt_hit *d
     return 0;
 }
 
+int launch_sample_hdri(const PtSceneDev &sc, const float *d_dirs, int64_t n, float *d_out, hipStream_t stream) {
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(sample_hdri_kernel, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream, sc, d_dirs, n, d_out);
+    PT_HIP(hipGetLastError());
+    return 0;
+}
+
+int launch_sample_material(const PtSceneDev &sc, int material, const float *d_uv, int64_t n, float *d_out, hipStream_t stream) {
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(sample_material_kernel, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream, sc, material, d_uv, n, d_out);
+    PT_HIP(hipGetLastError());
+    return 0;
+}
+
 int launch_camera_rays(const pt_camera &cam, uint32_t seed, int sample, float *d_rays, hipStream_t stream) {
     const int n = cam.res_x * cam.res_y;
     if (n <= 0) return 0;
@@ -563,13 +614,20 @@ int launch_camera_rays(const pt_camera &cam, uint32_t seed, int sample, float *d
     return 0;
 }
 
-int launch_render(RenderParams p, int n_cu, int max_queues, bool heavy, hipStream_t stream) {
-    const size_t lds = stack_bytes(p.sc.max_depth);
-    /* persistent grid: as many workgroups as stay resident (registers: `waves` waves per SIMD = as many
-     * workgroups of 256 threads per CU; LDS: 160 KiB / lds) */
+/* workgroups of the render kernel that stay resident per CU: bounded by registers (`waves` waves per SIMD = as
+ * many workgroups of 256 threads per CU) and by LDS (160 KiB / the stacks of one workgroup) */
+int render_workgroups_per_cu(int max_depth, bool heavy) {
+    const size_t lds = stack_bytes(max_depth);
     int per_cu = heavy ? kWavesHeavy : kWavesLight;
     const int by_lds = (int)((160 * 1024) / (lds ? lds : 1));
     if (by_lds < per_cu) per_cu = by_lds > 0 ? by_lds : 1;
+    return per_cu;
+}
+
+int launch_render(RenderParams p, int n_cu, int max_queues, bool heavy, hipStream_t stream) {
+    const size_t lds = stack_bytes(p.sc.max_depth);
+    /* persistent grid: as many workgroups as stay resident */
+    const int per_cu = render_workgroups_per_cu(p.sc.max_depth, heavy);
     int64_t blocks = (int64_t)n_cu * per_cu;
     const int64_t max_useful = ((int64_t)p.n_items * 64 + kBlock - 1) / kBlock;
     if (blocks > max_useful) blocks = max_useful;

@@ -254,9 +254,10 @@ static int run_separable(const float *d_in, float *d_tmp, float *d_out, int w, i
 
 struct DevSel {
     int prev = -1;
+    bool ok = true;
     explicit DevSel(int dev) {
         if (hipGetDevice(&prev) != hipSuccess) prev = -1;
-        if (prev != dev) (void)hipSetDevice(dev);
+        if (prev != dev) ok = hipSetDevice(dev) == hipSuccess;
     }
     ~DevSel() { if (prev >= 0) (void)hipSetDevice(prev); }
 };
@@ -348,6 +349,34 @@ int pt_image_add(int device, float *d_buf, const float *d_layer, int64_t n_pixel
     PT_HIP(hipGetLastError());
     return 0;
 }
+int pt_reduce_sum(int dst_device, float *d_dst, int n_src, const int *src_devices, const float *const *d_src, int64_t n_floats) {
+    if (!d_dst || !src_devices || !d_src) PT_FAIL("pt_reduce_sum: null argument");
+    if (n_src < 0 || n_floats < 0) PT_FAIL("pt_reduce_sum: negative count");
+    for (int i = 0; i < n_src; i++)
+        if (!d_src[i]) PT_FAIL("pt_reduce_sum: null source buffer");
+    if (n_src == 0 || n_floats == 0) return 0;
+    DevSel g(dst_device);
+    if (!g.ok) PT_FAIL("pt_reduce_sum: cannot select device");
+    const size_t bytes = (size_t)n_floats * sizeof(float);
+    float *d_tmp = nullptr;
+    PT_HIP(hipMalloc((void **)&d_tmp, bytes));
+    int rc = 0;
+    for (int i = 0; i < n_src && !rc; i++) {
+        /* the source devices have finished writing (the caller synchronised them); the copy crosses xGMI
+         * directly when the two GPUs are peers, and goes through the host otherwise */
+        hipError_t e = src_devices[i] == dst_device ? hipMemcpyAsync(d_tmp, d_src[i], bytes, hipMemcpyDeviceToDevice, nullptr)
+                                                    : hipMemcpyPeerAsync(d_tmp, dst_device, d_src[i], src_devices[i], bytes, nullptr);
+        if (e != hipSuccess) { rc = hip_fail(e, "peer copy", __FILE__, __LINE__); break; }
+        hipLaunchKernelGGL(add_kernel, dim3(grid1(n_floats)), dim3(kPostBlock), 0, nullptr, d_dst, d_tmp, n_floats, 1.0f);
+        e = hipGetLastError();
+        if (e != hipSuccess) rc = hip_fail(e, "add_kernel", __FILE__, __LINE__);
+    }
+    hipError_t e = hipStreamSynchronize(nullptr);
+    if (!rc && e != hipSuccess) rc = hip_fail(e, "hipStreamSynchronize", __FILE__, __LINE__);
+    (void)hipFree(d_tmp);
+    return rc;
+}
+
 int pt_apply_aces(int device, float *d_buf, int64_t n_pixels, void *stream) {
     if (!d_buf) PT_FAIL("pt_apply_aces: null argument");
     if (n_pixels <= 0) return 0;

@@ -14,6 +14,7 @@
 #include <fstream>
 #include <map>
 #include <sstream>
+#include <thread>
 
 #include "../../include/ptamd.h"
 
@@ -229,20 +230,43 @@ void GrayscaleTexture::set(const unsigned char *gray, ivec2 res) {
 }
 
 /* ================================================================== geometry */
-void AABB::recalculate(Vertex *vertices, int n_vertices) {      /* src/aabb.cu:7-22 */
-    vec3 _min(FLT_MAX, FLT_MAX, FLT_MAX);
-    vec3 _max(-FLT_MAX, -FLT_MAX, -FLT_MAX);
-    for (int i = 0; i < n_vertices; i++) {
-        vec3 p = vertices[i].position;
-        _min.x = (p.x < _min.x) ? p.x : _min.x;
-        _min.y = (p.y < _min.y) ? p.y : _min.y;
-        _min.z = (p.z < _min.z) ? p.z : _min.z;
-        _max.x = (p.x > _max.x) ? p.x : _max.x;
-        _max.y = (p.y > _max.y) ? p.y : _max.y;
-        _max.z = (p.z > _max.z) ? p.z : _max.z;
+namespace {
+
+/* componentwise bounds of a vertex array (min / max select one of their arguments: no rounding) */
+struct Extent {
+    vec3 lo = vec3(FLT_MAX), hi = vec3(-FLT_MAX);
+    void include(const vec3 &p) {
+        lo = vec3(std::fmin(lo.x, p.x), std::fmin(lo.y, p.y), std::fmin(lo.z, p.z));
+        hi = vec3(std::fmax(hi.x, p.x), std::fmax(hi.y, p.y), std::fmax(hi.z, p.z));
     }
-    this->min = _min - vec3(AABB_PADDING, AABB_PADDING, AABB_PADDING);
-    this->max = _max + vec3(AABB_PADDING, AABB_PADDING, AABB_PADDING);
+};
+
+/* a 3x3 matrix as three rows; apply() forms each output component as dot(v, row): x*rx + y*ry + z*rz in that
+ * order, the rounding sequence of the reference's per-vertex rotation (src/entity.cu:244-256) */
+struct Rows3 {
+    vec3 row[3];
+    vec3 apply(const vec3 &v) const { return vec3(dot(v, row[0]), dot(v, row[1]), dot(v, row[2])); }
+};
+
+/* R = Rz(rot.z) * Ry(rot.y) * Rx(rot.x) with the sines and cosines evaluated in double and narrowed
+ * (src/entity.cu:232-242: the unqualified cos / sin of that translation unit are the double overloads) */
+Rows3 euler_zyx(const vec3 &rot) {
+    const float cz = (float)std::cos((double)rot.z), sz = (float)std::sin((double)rot.z);
+    const float cy = (float)std::cos((double)rot.y), sy = (float)std::sin((double)rot.y);
+    const float cx = (float)std::cos((double)rot.x), sx = (float)std::sin((double)rot.x);
+    Rows3 m;
+    m.row[0] = vec3(cz * cy, cz * sy * sx - sz * cx, cz * sy * cx + sz * sx);
+    m.row[1] = vec3(sz * cy, sz * sy * sx + cz * cx, sz * sy * cx - cz * sx);
+    m.row[2] = vec3(-sy, cy * sx, cy * cx);
+    return m;
+}
+
+}  // namespace
+
+void AABB::recalculate(Vertex *vertices, int n_vertices) {      /* src/aabb.cu:7-22: padded bounds of the vertices */
+    Extent ext;
+    for (const Vertex *v = vertices; v != vertices + n_vertices; ++v) ext.include(v->position);
+    *this = AABB(ext.lo, ext.hi);
 }
 
 Entity::Entity(const std::string &path, Material *material) {   /* src/entity.cu:13-148 */
@@ -251,62 +275,55 @@ Entity::Entity(const std::string &path, Material *material) {   /* src/entity.cu
         std::cout << "cannot load " << path << " (missing, or not exactly one shape)" << std::endl;
         exit(1);
     }
-    const bool no_normals = (obj.vn.size() / 3) == 0;
-    const bool has_uv = obj.vt.size() != 0;
     this->n_vertices = obj.v.size() / 3;
     this->n_triangles = obj.face_sizes.size();
     this->n_uvs = obj.vt.size() / 2;
+    const size_t n_file_normals = obj.vn.size() / 3;
     this->vertices = new Vertex[this->n_vertices];
     this->triangles = new Triangle[this->n_triangles];
-    if (has_uv) this->uvs = new vec2[this->n_uvs];
-
-    vec3 mn(FLT_MAX, FLT_MAX, FLT_MAX), mx(-FLT_MAX, -FLT_MAX, -FLT_MAX);
-    for (size_t v = 0; v < this->n_vertices; v++) {
-        vec3 position(obj.v[3 * v], obj.v[3 * v + 1], obj.v[3 * v + 2]);
-        vec3 normal(0.0f, 0.0f, 0.0f);
-        /* the reference indexes vn by VERTEX id (src/entity.cu:58-65, a known flaw of it); kept,
-         * bounded by the number of normals present */
-        if (!no_normals && 3 * v + 2 < obj.vn.size()) {
-            normal = vec3(obj.vn[3 * v], obj.vn[3 * v + 1], obj.vn[3 * v + 2]);
-            normal.normalize();
-        }
-        mn.x = (position.x < mn.x) ? position.x : mn.x;
-        mn.y = (position.y < mn.y) ? position.y : mn.y;
-        mn.z = (position.z < mn.z) ? position.z : mn.z;
-        mx.x = (position.x > mx.x) ? position.x : mx.x;
-        mx.y = (position.y > mx.y) ? position.y : mx.y;
-        mx.z = (position.z > mx.z) ? position.z : mx.z;
-        this->vertices[v] = Vertex(position, normal);
+    if (this->n_uvs) {
+        this->uvs = new vec2[this->n_uvs];
+        for (size_t t = 0; t < this->n_uvs; t++) this->uvs[t] = vec2(obj.vt[2 * t], obj.vt[2 * t + 1]);
     }
-    for (size_t t = 0; t < this->n_uvs; t++) this->uvs[t] = vec2(obj.vt[2 * t], obj.vt[2 * t + 1]);
 
-    size_t off = 0;
-    for (size_t f = 0; f < this->n_triangles; f++) {
+    Extent ext;
+    for (size_t v = 0; v < this->n_vertices; v++) {
+        Vertex &out = this->vertices[v];
+        out.position = vec3(obj.v[3 * v], obj.v[3 * v + 1], obj.v[3 * v + 2]);
+        out.normal = vec3(0.0f);
+        /* the reference pairs vn entries with vertices by VERTEX index (src/entity.cu:58-65, a known flaw of
+         * it); kept, bounded by the number of normals present */
+        if (v < n_file_normals) out.normal = vec3(obj.vn[3 * v], obj.vn[3 * v + 1], obj.vn[3 * v + 2]).normalized();
+        ext.include(out.position);
+    }
+
+    const int *corner = obj.idx.data();       /* per face corner: vertex index, texcoord index */
+    for (size_t f = 0; f < this->n_triangles; f++, corner += 6) {
         if (obj.face_sizes[f] != 3) {
             std::cerr << "OBJ file faces must be triangles" << std::endl;
             exit(1);
         }
-        this->triangles[f] = Triangle(obj.idx[off + 0], obj.idx[off + 2], obj.idx[off + 4], obj.idx[off + 1], obj.idx[off + 3], obj.idx[off + 5]);
-        const Triangle &tr = this->triangles[f];
-        if (tr.idx_a < 0 || tr.idx_b < 0 || tr.idx_c < 0 || (size_t)tr.idx_a >= n_vertices || (size_t)tr.idx_b >= n_vertices ||
-            (size_t)tr.idx_c >= n_vertices) {
-            std::cerr << "OBJ face references a missing vertex" << std::endl;
-            exit(1);
-        }
-        if (no_normals) {     /* src/entity.cu:110-123 */
-            vec3 v0 = this->vertices[tr.idx_a].position, v1 = this->vertices[tr.idx_b].position, v2 = this->vertices[tr.idx_c].position;
-            vec3 t_normal = cross(v1 - v0, v2 - v0).normalized();
-            this->vertices[tr.idx_a].normal = this->vertices[tr.idx_a].normal + t_normal;
-            this->vertices[tr.idx_b].normal = this->vertices[tr.idx_b].normal + t_normal;
-            this->vertices[tr.idx_c].normal = this->vertices[tr.idx_c].normal + t_normal;
-        }
-        off += 6;
+        const Triangle tr(corner[0], corner[2], corner[4], corner[1], corner[3], corner[5]);
+        for (int vi : {tr.idx_a, tr.idx_b, tr.idx_c})
+            if (vi < 0 || (size_t)vi >= this->n_vertices) {
+                std::cerr << "OBJ face references a missing vertex" << std::endl;
+                exit(1);
+            }
+        this->triangles[f] = tr;
     }
-    if (no_normals)
-        for (size_t i = 0; i < this->n_vertices; i++) this->vertices[i].normal.normalize();
+    if (n_file_normals == 0) {
+        /* no vn in the file: every vertex gets the normalised sum of the unit normals of its faces, faces taken
+         * in file order (src/entity.cu:110-133; the order fixes the fp32 sums) */
+        for (size_t f = 0; f < this->n_triangles; f++) {
+            Vertex *corner_v[3] = {&vertices[triangles[f].idx_a], &vertices[triangles[f].idx_b], &vertices[triangles[f].idx_c]};
+            const vec3 face = cross(corner_v[1]->position - corner_v[0]->position, corner_v[2]->position - corner_v[0]->position).normalized();
+            for (Vertex *v : corner_v) v->normal = v->normal + face;
+        }
+        for (size_t v = 0; v < this->n_vertices; v++) this->vertices[v].normal.normalize();
+    }
 
-    this->aabb = AABB(mn, mx);
-    this->center = vec3((mn.x + mx.x) / 2, (mn.y + mx.y) / 2, (mn.z + mx.z) / 2);
+    this->aabb = AABB(ext.lo, ext.hi);
+    this->center = (ext.lo + ext.hi) / 2;           /* midpoint of the unpadded box (src/entity.cu:139-143) */
     this->material = material;
     this->shape = TRIANGLE_MESH;
 }
@@ -324,50 +341,88 @@ Entity::~Entity() {
     delete[] this->uvs;
 }
 
-void Entity::construct_octree() { this->octree_requested = true; }
+void Entity::construct_octree(int depth) {
+    if (depth < 1 || depth > OCTREE_DEPTH_LIMIT) {
+        std::cerr << "construct_octree: depth must be in [1, " << OCTREE_DEPTH_LIMIT << "]" << std::endl;
+        exit(1);
+    }
+    this->requested_octree_depth = depth;
+}
 
-void Entity::print() {      /* src/entity.cu:175-180 */
+void Entity::print() {      /* src/entity.cu:175-180: centre, then the padded extent per axis */
     std::cout << "center: " << this->center << std::endl;
-    std::cout << "x: " << this->aabb.min.x << " to " << this->aabb.max.x << std::endl;
-    std::cout << "y: " << this->aabb.min.y << " to " << this->aabb.max.y << std::endl;
-    std::cout << "z: " << this->aabb.min.z << " to " << this->aabb.max.z << std::endl;
+    const float lo[3] = {aabb.min.x, aabb.min.y, aabb.min.z}, hi[3] = {aabb.max.x, aabb.max.y, aabb.max.z};
+    for (int axis = 0; axis < 3; axis++) std::cout << "xyz"[axis] << ": " << lo[axis] << " to " << hi[axis] << std::endl;
 }
 
-void Entity::scale(float factor) {      /* src/entity.cu:185-202 */
-    if (this->shape == SPHERE) { radius *= factor; return; }
-    for (size_t i = 0; i < n_vertices; i++) {
-        vec3 pos = vertices[i].position;
-        pos = ((pos - this->center) * factor) + this->center;
-        vertices[i].position = pos;
-    }
+/* applies `f` to every vertex of a mesh and refreshes its bounding box */
+template <typename F>
+void Entity::transform_vertices(F f) {
+    for (size_t i = 0; i < this->n_vertices; i++) f(this->vertices[i]);
     this->aabb.recalculate(this->vertices, (int)this->n_vertices);
 }
 
-void Entity::translate(vec3 delta) {    /* src/entity.cu:207-222 */
+void Entity::scale(float factor) {      /* src/entity.cu:185-202: about the centre; normals keep their direction */
+    if (this->shape == SPHERE) {
+        this->radius *= factor;
+        return;
+    }
+    const vec3 c = this->center;
+    transform_vertices([&](Vertex &v) { v.position = ((v.position - c) * factor) + c; });
+}
+
+void Entity::translate(vec3 delta) {    /* src/entity.cu:207-222: the centre moves along */
     this->center = this->center + delta;
-    if (this->shape == TRIANGLE_MESH) {
-        for (size_t i = 0; i < n_vertices; i++) vertices[i].position = vertices[i].position + delta;
-        this->aabb.recalculate(this->vertices, (int)this->n_vertices);
-    }
+    if (this->shape == TRIANGLE_MESH) transform_vertices([&](Vertex &v) { v.position = v.position + delta; });
 }
 
-void Entity::rotate(vec3 rot) {         /* src/entity.cu:227-258 */
+void Entity::rotate(vec3 rot) {         /* src/entity.cu:227-258: about the centre, normals turn with the mesh */
     if (this->shape == SPHERE) return;
-    /* the global ::cos / ::sin of the reference's translation unit are the double versions; narrowed */
-    float cos_a = (float)std::cos((double)rot.z), sin_a = (float)std::sin((double)rot.z);
-    float cos_b = (float)std::cos((double)rot.y), sin_b = (float)std::sin((double)rot.y);
-    float cos_g = (float)std::cos((double)rot.x), sin_g = (float)std::sin((double)rot.x);
-    vec3 R0(cos_a * cos_b, cos_a * sin_b * sin_g - sin_a * cos_g, cos_a * sin_b * cos_g + sin_a * sin_g);
-    vec3 R1(sin_a * cos_b, sin_a * sin_b * sin_g + cos_a * cos_g, sin_a * sin_b * cos_g - cos_a * sin_g);
-    vec3 R2(-sin_b, cos_b * sin_g, cos_b * cos_g);
-    for (size_t i = 0; i < this->n_vertices; i++) {
-        vec3 v = this->vertices[i].position - this->center;
-        v = vec3(dot(v, R0), dot(v, R1), dot(v, R2));
-        this->vertices[i].position = v + this->center;
-        vec3 n = this->vertices[i].normal;
-        this->vertices[i].normal = vec3(dot(n, R0), dot(n, R1), dot(n, R2));
+    const Rows3 R = euler_zyx(rot);
+    const vec3 c = this->center;
+    transform_vertices([&](Vertex &v) {
+        v.position = R.apply(v.position - c) + c;
+        v.normal = R.apply(v.normal);
+    });
+}
+
+namespace {
+/* positions / normals of a mesh entity as the flat float arrays the C ABI takes */
+void flatten_vertices(const Entity &e, std::vector<float> &pos, std::vector<float> &nrm) {
+    const size_t nv = e.vertex_count();
+    pos.resize(3 * nv);
+    nrm.resize(3 * nv);
+    for (size_t i = 0; i < nv; i++) {
+        const Vertex &v = e.vertex_data()[i];
+        pos[3 * i] = v.position.x; pos[3 * i + 1] = v.position.y; pos[3 * i + 2] = v.position.z;
+        nrm[3 * i] = v.normal.x; nrm[3 * i + 1] = v.normal.y; nrm[3 * i + 2] = v.normal.z;
     }
-    this->aabb.recalculate(this->vertices, (int)this->n_vertices);
+}
+static_assert(sizeof(Triangle) == 6 * sizeof(int), "Triangle is six ints");
+static_assert(sizeof(vec2) == 2 * sizeof(float), "vec2 is two floats");
+}  // namespace
+
+Entity::OctreeStatistics Entity::octree_statistics() const {
+    OctreeStatistics st;
+    if (this->shape != TRIANGLE_MESH || this->requested_octree_depth == 0) return st;
+    pt_scene *host_only = nullptr;
+    PT_CHECK(pt_scene_create(-1, &host_only));
+    pt_material_desc md;
+    memset(&md, 0, sizeof md);
+    int mat = -1, ent = -1;
+    PT_CHECK(pt_scene_add_material(host_only, &md, &mat));
+    std::vector<float> pos, nrm;
+    flatten_vertices(*this, pos, nrm);
+    PT_CHECK(pt_scene_add_mesh(host_only, pos.data(), nrm.data(), (int)n_vertices, (const int32_t *)triangles, (int)n_triangles,
+                               (const float *)uvs, (int)n_uvs, mat, requested_octree_depth, &ent));
+    pt_octree_info info;
+    PT_CHECK(pt_scene_octree_info(host_only, ent, &info));
+    st.nodes_per_depth.assign(info.nodes_per_depth, info.nodes_per_depth + info.max_depth + 1);
+    st.n_nodes = info.n_nodes;
+    st.n_leaf_refs = info.n_leaf_refs;
+    st.max_leaf = info.max_leaf;
+    PT_CHECK(pt_scene_destroy(host_only));
+    return st;
 }
 
 /* ================================================================== scene */
@@ -398,56 +453,56 @@ void Scene::add_entity(Entity *entity) { this->entities.push_back(entity); }
 
 /* replaces the per-object cudaMalloc / cudaMemcpy cascade of src/scene.cu:67-90, src/entity.cu:263-303,
  * src/octree.cu:24-41, src/material.cu:32-43, src/texture.cu:29-49 with one flattened upload */
-void Scene::copy_to_device() {
-    if (this->on_device) this->free_from_device();
-    PT_CHECK(pt_scene_create(this->device, &this->handle));
-    std::map<Material *, int> mat_ids;      /* materials may be shared between entities (src/entity.cu:363) */
-    for (Entity *e : this->entities) {
-        if (mat_ids.find(e->material) == mat_ids.end()) {
-            Material *m = e->material;
-            pt_material_desc d;
-            memset(&d, 0, sizeof d);
-            d.albedo[0] = m->albedo.x; d.albedo[1] = m->albedo.y; d.albedo[2] = m->albedo.z;
-            d.specular[0] = m->specular.x; d.specular[1] = m->specular.y; d.specular[2] = m->specular.z;
-            d.emission = m->emission;
-            d.smoothness = m->smoothness;
-            d.smooth_shading = m->smooth_shading ? 1 : 0;
-            d.albedo_map = m->albedo_map.data; d.albedo_w = m->albedo_map.resolution.x; d.albedo_h = m->albedo_map.resolution.y;
-            d.specular_map = m->specular_map.data; d.specular_w = m->specular_map.resolution.x; d.specular_h = m->specular_map.resolution.y;
-            d.normal_map = m->normal_map.data; d.normal_w = m->normal_map.resolution.x; d.normal_h = m->normal_map.resolution.y;
-            d.smoothness_map = m->smoothness_map.data; d.smoothness_w = m->smoothness_map.resolution.x; d.smoothness_h = m->smoothness_map.resolution.y;
-            int id = -1;
-            PT_CHECK(pt_scene_add_material(this->handle, &d, &id));
-            mat_ids[m] = id;
-            m->on_device = true;
-        }
+pt_scene *Scene::build_on(int dev) const {
+    pt_scene *h = nullptr;
+    PT_CHECK(pt_scene_create(dev, &h));
+    std::map<const Material *, int> mat_ids;      /* materials may be shared between entities (src/entity.cu:363) */
+    for (const Entity *e : this->entities) {
+        const Material *m = e->material;
+        if (mat_ids.count(m)) continue;
+        pt_material_desc d;
+        memset(&d, 0, sizeof d);
+        d.albedo[0] = m->albedo.x; d.albedo[1] = m->albedo.y; d.albedo[2] = m->albedo.z;
+        d.specular[0] = m->specular.x; d.specular[1] = m->specular.y; d.specular[2] = m->specular.z;
+        d.emission = m->emission;
+        d.smoothness = m->smoothness;
+        d.smooth_shading = m->smooth_shading ? 1 : 0;
+        d.albedo_map = m->albedo_map.data; d.albedo_w = m->albedo_map.resolution.x; d.albedo_h = m->albedo_map.resolution.y;
+        d.specular_map = m->specular_map.data; d.specular_w = m->specular_map.resolution.x; d.specular_h = m->specular_map.resolution.y;
+        d.normal_map = m->normal_map.data; d.normal_w = m->normal_map.resolution.x; d.normal_h = m->normal_map.resolution.y;
+        d.smoothness_map = m->smoothness_map.data; d.smoothness_w = m->smoothness_map.resolution.x; d.smoothness_h = m->smoothness_map.resolution.y;
+        int id = -1;
+        PT_CHECK(pt_scene_add_material(h, &d, &id));
+        mat_ids[m] = id;
     }
-    for (Entity *e : this->entities) {
+    std::vector<float> pos, nrm;
+    for (const Entity *e : this->entities) {
         const int mat = mat_ids[e->material];
         if (e->shape == SPHERE) {
             const vec3 c = e->get_center();
             const float cc[3] = {c.x, c.y, c.z};
-            PT_CHECK(pt_scene_add_sphere(this->handle, cc, e->get_radius(), mat, nullptr));
+            PT_CHECK(pt_scene_add_sphere(h, cc, e->get_radius(), mat, nullptr));
         } else {
-            const size_t nv = e->vertex_count(), nt = e->triangle_count();
-            std::vector<float> pos(3 * nv), nrm(3 * nv);
-            for (size_t i = 0; i < nv; i++) {
-                const Vertex &v = e->vertex_data()[i];
-                pos[3 * i] = v.position.x; pos[3 * i + 1] = v.position.y; pos[3 * i + 2] = v.position.z;
-                nrm[3 * i] = v.normal.x; nrm[3 * i + 1] = v.normal.y; nrm[3 * i + 2] = v.normal.z;
-            }
-            static_assert(sizeof(Triangle) == 6 * sizeof(int), "Triangle is six ints");
-            static_assert(sizeof(vec2) == 2 * sizeof(float), "vec2 is two floats");
-            PT_CHECK(pt_scene_add_mesh(this->handle, pos.data(), nrm.data(), (int)nv, (const int32_t *)e->triangle_data(), (int)nt,
-                                       (const float *)e->uv_data(), (int)e->uv_count(), mat, e->wants_octree() ? MAX_OCTREE_DEPTH : 0,
+            flatten_vertices(*e, pos, nrm);
+            PT_CHECK(pt_scene_add_mesh(h, pos.data(), nrm.data(), (int)e->vertex_count(), (const int32_t *)e->triangle_data(),
+                                       (int)e->triangle_count(), (const float *)e->uv_data(), (int)e->uv_count(), mat, e->octree_depth(),
                                        nullptr));
         }
-        e->on_device = true;
     }
     if (has_hdri)
-        PT_CHECK(pt_scene_set_hdri(this->handle, this->hdri.data(), this->hdri_width, this->hdri_height, this->hdri_exposure,
-                                   this->hdri_contrast, this->hdri_rot_offset, this->use_smooth_hdri ? 1 : 0));
-    PT_CHECK(pt_scene_commit(this->handle));
+        PT_CHECK(pt_scene_set_hdri(h, this->hdri.data(), this->hdri_width, this->hdri_height, this->hdri_exposure, this->hdri_contrast,
+                                   this->hdri_rot_offset, this->use_smooth_hdri ? 1 : 0));
+    PT_CHECK(pt_scene_commit(h));
+    return h;
+}
+
+void Scene::copy_to_device() {
+    if (this->on_device) this->free_from_device();
+    this->handle = this->build_on(this->device);
+    for (Entity *e : this->entities) {
+        e->on_device = true;
+        e->material->on_device = true;
+    }
     this->on_device = true;
     this->n_entities = this->entities.size();
 }
@@ -469,49 +524,95 @@ void Renderer::set_samples_per_pixel(unsigned int spp) {      /* src/renderer.cu
     this->n_samples_per_pass = per > 1 ? per : 1;
 }
 
-/* src/renderer.cu:192-312: upload, trace n_split * n_blocks * n_samples_per_pass samples per pixel
- * into n_split split buffers, compound, then the fixed post chain -- all device resident here. */
-Image Renderer::render(const Camera &camera, Scene &scene) {
-    const int64_t n_pixels = (int64_t)camera.resolution.x * camera.resolution.y;
-    const unsigned int spp = this->n_split_buffers * this->n_blocks_per_tile * this->n_samples_per_pass;
-    std::cout << "copying scene to device..." << std::endl;
-    scene.copy_to_device();
-    std::cout << "done!" << std::endl;
-    const int dev = scene.device;
-    char name[256];
-    if (pt_device_name(dev, name, sizeof name) == 0) printf("Device %d: \"%s\"\n", dev, name);
+namespace {
 
-    void *d_split = nullptr, *d_sum = nullptr, *d_out = nullptr;
-    const size_t img_bytes = (size_t)n_pixels * sizeof(vec3);
-    PT_CHECK(pt_malloc(dev, img_bytes * this->n_split_buffers, &d_split));
-    PT_CHECK(pt_malloc(dev, img_bytes, &d_sum));
-    PT_CHECK(pt_malloc(dev, img_bytes, &d_out));
-    PT_CHECK(pt_memset(dev, d_split, 0, img_bytes * this->n_split_buffers, nullptr));    /* the reference never clears it */
-
+pt_camera to_abi(const Camera &camera) {
     pt_camera cam;
     cam.position[0] = camera.position.x; cam.position[1] = camera.position.y; cam.position[2] = camera.position.z;
     cam.direction[0] = camera.direction.x; cam.direction[1] = camera.direction.y; cam.direction[2] = camera.direction.z;
     cam.up[0] = camera.up.x; cam.up[1] = camera.up.y; cam.up[2] = camera.up.z;
     cam.res_x = camera.resolution.x; cam.res_y = camera.resolution.y;
     cam.focal_length = camera.focal_length; cam.aperture = camera.aperture; cam.focus_distance = camera.focus_distance;
+    return cam;
+}
+
+/* one GPU's share of a render: samples [begin, end) of every pixel into fresh split buffers, compounded into
+ * *d_sum_out (device memory on `dev`, owned by the caller afterwards) */
+void render_share(pt_scene *scene, int dev, const pt_camera &cam, unsigned seed, int begin, int end, int n_split, void **d_sum_out) {
+    const int64_t n_pixels = (int64_t)cam.res_x * cam.res_y;
+    const size_t img_bytes = (size_t)n_pixels * sizeof(vec3);
+    void *d_split = nullptr, *d_sum = nullptr;
+    PT_CHECK(pt_malloc(dev, img_bytes * n_split, &d_split));
+    PT_CHECK(pt_malloc(dev, img_bytes, &d_sum));
+    PT_CHECK(pt_memset(dev, d_split, 0, img_bytes * n_split, nullptr));    /* the reference never clears its buffer */
+    PT_CHECK(pt_render_accumulate(scene, &cam, seed, begin, end, n_split, (float *)d_split, nullptr, nullptr));
+    PT_CHECK(pt_compound_buffers(dev, (const float *)d_split, (float *)d_sum, n_pixels, n_split, nullptr));
+    PT_CHECK(pt_stream_synchronize(dev, nullptr));
+    PT_CHECK(pt_free(dev, d_split));
+    *d_sum_out = d_sum;
+}
+
+}  // namespace
+
+/* src/renderer.cu:192-312: upload, trace n_split * n_blocks * n_samples_per_pass samples per pixel into n_split
+ * split buffers, compound, then the fixed post chain -- all device resident here, on one GPU or several. */
+Image Renderer::render(const Camera &camera, Scene &scene) {
+    const int64_t n_pixels = (int64_t)camera.resolution.x * camera.resolution.y;
+    const size_t img_bytes = (size_t)n_pixels * sizeof(vec3);
+    const unsigned int spp = this->n_split_buffers * this->n_blocks_per_tile * this->n_samples_per_pass;
+    const int n_split = (int)this->n_split_buffers;
+    const pt_camera cam = to_abi(camera);
+    std::vector<int> devs = this->devices;
+    if (devs.empty()) devs.push_back(scene.device);
+    const int n_dev = (int)devs.size(), root = devs[0];
+
+    std::cout << "copying scene to device..." << std::endl;
+    std::vector<pt_scene *> handles(n_dev, nullptr);
+    if (n_dev == 1 && root == scene.device) {
+        scene.copy_to_device();
+        handles[0] = scene.device_scene();
+    }
+    std::cout << "done!" << std::endl;
+    char name[256];
+    for (int d : devs)
+        if (pt_device_name(d, name, sizeof name) == 0) printf("Device %d: \"%s\"\n", d, name);
 
     std::cout << "start render" << std::endl;
-    PT_CHECK(pt_render_accumulate(scene.device_scene(), &cam, this->seed, 0, (int)spp, (int)this->n_split_buffers, (float *)d_split,
-                                  nullptr, nullptr));
-    PT_CHECK(pt_compound_buffers(dev, (const float *)d_split, (float *)d_sum, n_pixels, (int)this->n_split_buffers, nullptr));
-    PT_CHECK(pt_post_chain(dev, (const float *)d_sum, (float *)d_out, camera.resolution.x, camera.resolution.y, spp, nullptr));
+    std::vector<void *> d_sums(n_dev, nullptr);
+    if (handles[0]) {
+        render_share(handles[0], root, cam, this->seed, 0, (int)spp, n_split, &d_sums[0]);
+    } else {
+        /* one host thread per GPU: copy the scene there, render the rank's contiguous share of the samples */
+        std::vector<std::thread> workers;
+        for (int r = 0; r < n_dev; r++)
+            workers.emplace_back([&, r]() {
+                handles[r] = scene.build_on(devs[r]);
+                const int begin = (int)(((long long)spp * r) / n_dev), end = (int)(((long long)spp * (r + 1)) / n_dev);
+                render_share(handles[r], devs[r], cam, this->seed, begin, end, n_split, &d_sums[r]);
+            });
+        for (std::thread &w : workers) w.join();
+        /* root += the other GPUs' sums, in list order (peer copies; fixed order: reproducible bits) */
+        if (n_dev > 1)
+            PT_CHECK(pt_reduce_sum(root, (float *)d_sums[0], n_dev - 1, devs.data() + 1, (const float *const *)(d_sums.data() + 1), n_pixels * 3));
+    }
 
+    void *d_out = nullptr;
+    PT_CHECK(pt_malloc(root, img_bytes, &d_out));
+    PT_CHECK(pt_post_chain(root, (const float *)d_sums[0], (float *)d_out, camera.resolution.x, camera.resolution.y, spp, nullptr));
     std::vector<vec3> result_pixels((size_t)n_pixels);
-    PT_CHECK(pt_download(dev, result_pixels.data(), d_out, img_bytes, nullptr));
+    PT_CHECK(pt_download(root, result_pixels.data(), d_out, img_bytes, nullptr));
     this->last_hdr_sum.resize((size_t)n_pixels);
-    PT_CHECK(pt_download(dev, this->last_hdr_sum.data(), d_sum, img_bytes, nullptr));
+    PT_CHECK(pt_download(root, this->last_hdr_sum.data(), d_sums[0], img_bytes, nullptr));
     this->last_samples_per_pixel = spp;
-    PT_CHECK(pt_free(dev, d_split));
-    PT_CHECK(pt_free(dev, d_sum));
-    PT_CHECK(pt_free(dev, d_out));
+    PT_CHECK(pt_free(root, d_out));
+    for (int r = 0; r < n_dev; r++) PT_CHECK(pt_free(devs[r], d_sums[r]));
 
     std::cout << "freeing scene from device..." << std::endl;
-    scene.free_from_device();
+    if (n_dev == 1 && root == scene.device) {
+        scene.free_from_device();
+    } else {
+        for (pt_scene *h : handles) PT_CHECK(pt_scene_destroy(h));
+    }
     std::cout << "done!" << std::endl;
     return Image(result_pixels, camera.resolution);
 }
@@ -540,95 +641,91 @@ void Kernel::print() {       /* src/post_processing.cu:11-26 */
 }
 
 namespace {
+int g_post_device = 0;      /* GPU of the free post-processing functions */
+
 /* runs one device image operation on a host vector: upload, op, download (the reference's
  * apply_filter does the same round trip, src/post_processing.cu:105-131) */
 template <typename F>
 void on_device(std::vector<vec3> &buf, F op) {
+    const int dev = g_post_device;
     const size_t bytes = buf.size() * sizeof(vec3);
     void *d = nullptr;
-    PT_CHECK(pt_malloc(0, bytes, &d));
-    PT_CHECK(pt_upload(0, d, buf.data(), bytes, nullptr));
-    op((float *)d);
-    PT_CHECK(pt_download(0, buf.data(), d, bytes, nullptr));
-    PT_CHECK(pt_free(0, d));
+    PT_CHECK(pt_malloc(dev, bytes, &d));
+    PT_CHECK(pt_upload(dev, d, buf.data(), bytes, nullptr));
+    op(dev, (float *)d);
+    PT_CHECK(pt_download(dev, buf.data(), d, bytes, nullptr));
+    PT_CHECK(pt_free(dev, d));
 }
+
+/* device copy of a host image on the post-processing GPU; freed by the destructor */
+struct DeviceImage {
+    int dev;
+    void *p = nullptr;
+    DeviceImage(const void *host, size_t bytes) : dev(g_post_device) {
+        PT_CHECK(pt_malloc(dev, bytes, &p));
+        if (host) PT_CHECK(pt_upload(dev, p, host, bytes, nullptr));
+    }
+    ~DeviceImage() { (void)pt_free(dev, p); }
+    float *f() const { return (float *)p; }
+};
 } // namespace
+
+void set_post_processing_device(int device) { g_post_device = device; }
+int post_processing_device() { return g_post_device; }
 
 void apply_filter(std::vector<vec3> &buf, ivec2 resolution, const Kernel &kernel, FilterType filter_type) {
     const size_t bytes = buf.size() * sizeof(vec3);
-    void *d_in = nullptr, *d_out = nullptr;
-    PT_CHECK(pt_malloc(0, bytes, &d_in));
-    PT_CHECK(pt_malloc(0, bytes, &d_out));
-    PT_CHECK(pt_upload(0, d_in, buf.data(), bytes, nullptr));
-    PT_CHECK(pt_apply_filter(0, (const float *)d_in, (float *)d_out, resolution.x, resolution.y, kernel.taps.data(), (int)kernel.size,
+    DeviceImage in(buf.data(), bytes), out(nullptr, bytes);
+    PT_CHECK(pt_apply_filter(in.dev, in.f(), out.f(), resolution.x, resolution.y, kernel.taps.data(), (int)kernel.size,
                              filter_type == BILATERAL ? 1 : 0, nullptr));
-    PT_CHECK(pt_download(0, buf.data(), d_out, bytes, nullptr));
-    PT_CHECK(pt_free(0, d_in));
-    PT_CHECK(pt_free(0, d_out));
+    PT_CHECK(pt_download(out.dev, buf.data(), out.p, bytes, nullptr));
 }
 
 void compound_buffers(std::vector<vec3> &out_image, const std::vector<vec3> &in_buf, unsigned int n_split_buffers) {
     const size_t n = out_image.size();      /* the reference uses capacity(); size() is what it means */
     assert(in_buf.size() >= n * n_split_buffers);
-    void *d_in = nullptr, *d_out = nullptr;
-    PT_CHECK(pt_malloc(0, n * n_split_buffers * sizeof(vec3), &d_in));
-    PT_CHECK(pt_malloc(0, n * sizeof(vec3), &d_out));
-    PT_CHECK(pt_upload(0, d_in, in_buf.data(), n * n_split_buffers * sizeof(vec3), nullptr));
-    PT_CHECK(pt_compound_buffers(0, (const float *)d_in, (float *)d_out, (int64_t)n, (int)n_split_buffers, nullptr));
-    PT_CHECK(pt_download(0, out_image.data(), d_out, n * sizeof(vec3), nullptr));
-    PT_CHECK(pt_free(0, d_in));
-    PT_CHECK(pt_free(0, d_out));
+    DeviceImage in(in_buf.data(), n * n_split_buffers * sizeof(vec3)), out(nullptr, n * sizeof(vec3));
+    PT_CHECK(pt_compound_buffers(in.dev, in.f(), out.f(), (int64_t)n, (int)n_split_buffers, nullptr));
+    PT_CHECK(pt_download(out.dev, out_image.data(), out.p, n * sizeof(vec3), nullptr));
 }
 
 void normalize_image(std::vector<vec3> &buf, unsigned int n_samples_per_pixel) {
-    on_device(buf, [&](float *d) { PT_CHECK(pt_normalize_image(0, d, (int64_t)buf.size(), n_samples_per_pixel, nullptr)); });
+    on_device(buf, [&](int dev, float *d) { PT_CHECK(pt_normalize_image(dev, d, (int64_t)buf.size(), n_samples_per_pixel, nullptr)); });
 }
 void gamma_correct(std::vector<vec3> &buf, float gamma) {
-    on_device(buf, [&](float *d) { PT_CHECK(pt_gamma_correct(0, d, (int64_t)buf.size(), gamma, nullptr)); });
+    on_device(buf, [&](int dev, float *d) { PT_CHECK(pt_gamma_correct(dev, d, (int64_t)buf.size(), gamma, nullptr)); });
 }
 void apply_aces(std::vector<vec3> &buf) {
-    on_device(buf, [&](float *d) { PT_CHECK(pt_apply_aces(0, d, (int64_t)buf.size(), nullptr)); });
+    on_device(buf, [&](int dev, float *d) { PT_CHECK(pt_apply_aces(dev, d, (int64_t)buf.size(), nullptr)); });
 }
 void image_add(std::vector<vec3> &buf, const std::vector<vec3> &layer, float opacity) {
     assert(buf.size() == layer.size());
-    const size_t bytes = buf.size() * sizeof(vec3);
-    void *d_l = nullptr;
-    PT_CHECK(pt_malloc(0, bytes, &d_l));
-    PT_CHECK(pt_upload(0, d_l, layer.data(), bytes, nullptr));
-    on_device(buf, [&](float *d) { PT_CHECK(pt_image_add(0, d, (const float *)d_l, (int64_t)buf.size(), opacity, nullptr)); });
-    PT_CHECK(pt_free(0, d_l));
+    DeviceImage l(layer.data(), layer.size() * sizeof(vec3));
+    on_device(buf, [&](int dev, float *d) { PT_CHECK(pt_image_add(dev, d, l.f(), (int64_t)buf.size(), opacity, nullptr)); });
 }
 std::vector<vec3> apply_threshold(const std::vector<vec3> &in_buf, float threshold) {
     std::vector<vec3> result(in_buf.size());
     const size_t bytes = in_buf.size() * sizeof(vec3);
-    void *d_in = nullptr, *d_out = nullptr;
-    PT_CHECK(pt_malloc(0, bytes, &d_in));
-    PT_CHECK(pt_malloc(0, bytes, &d_out));
-    PT_CHECK(pt_upload(0, d_in, in_buf.data(), bytes, nullptr));
-    PT_CHECK(pt_apply_threshold(0, (const float *)d_in, (float *)d_out, (int64_t)in_buf.size(), threshold, nullptr));
-    PT_CHECK(pt_download(0, result.data(), d_out, bytes, nullptr));
-    PT_CHECK(pt_free(0, d_in));
-    PT_CHECK(pt_free(0, d_out));
+    DeviceImage in(in_buf.data(), bytes), out(nullptr, bytes);
+    PT_CHECK(pt_apply_threshold(in.dev, in.f(), out.f(), (int64_t)in_buf.size(), threshold, nullptr));
+    PT_CHECK(pt_download(out.dev, result.data(), out.p, bytes, nullptr));
     return result;
 }
 
 /* ================================================================== io */
-void save_ppm(const std::string &filepath, const Image &img) {      /* src/io.cu:15-39 */
-    FILE *fp = fopen(filepath.c_str(), "w");
+void save_ppm(const std::string &filepath, const Image &img) {      /* src/io.cu:15-39: binary P6, min(x, 0.999) * 255 truncated */
+    const size_t n_pixels = (size_t)img.resolution.x * img.resolution.y;
+    std::vector<unsigned char> bytes(3 * n_pixels);
+    for (size_t i = 0; i < n_pixels; i++) {
+        const float rgb[3] = {img.buf[i].x, img.buf[i].y, img.buf[i].z};
+        for (int c = 0; c < 3; c++) bytes[3 * i + c] = (unsigned char)(std::fmin(rgb[c], 0.999f) * 255);
+    }
+    FILE *fp = fopen(filepath.c_str(), "wb");
     if (!fp) {
         fprintf(stderr, "cannot write %s\n", filepath.c_str());
         exit(1);
     }
-    fputs("P6\n", fp);
-    fputs("# Generated by ptamd\n", fp);
-    fprintf(fp, "%d %d\n", img.resolution.x, img.resolution.y);
-    fprintf(fp, "%d\n", 255);
-    for (int i = 0; i < img.resolution.x * img.resolution.y; i++) {
-        unsigned char color[3];
-        color[0] = (unsigned char)(((img.buf[i].x < 0.999f) ? img.buf[i].x : 0.999f) * 255);
-        color[1] = (unsigned char)(((img.buf[i].y < 0.999f) ? img.buf[i].y : 0.999f) * 255);
-        color[2] = (unsigned char)(((img.buf[i].z < 0.999f) ? img.buf[i].z : 0.999f) * 255);
-        fwrite(color, sizeof(char), 3, fp);
-    }
+    fprintf(fp, "P6\n# Generated by ptamd\n%d %d\n255\n", img.resolution.x, img.resolution.y);
+    fwrite(bytes.data(), 1, bytes.size(), fp);
     fclose(fp);
 }

@@ -22,7 +22,7 @@
  * Deviations (each is a place where the reference misbehaves): Entity::construct_octree() only
  * records that an octree is wanted -- it is built from the vertices as they are when the scene is
  * copied to the device, so a transform issued after construct_octree() is honoured instead of
- * leaving a stale tree; textures are read from binary PPM / PGM files (the reference's stb_image
+ * leaving a stale tree (Entity::octree_statistics() builds it on demand for inspection); textures are read from binary PPM / PGM files (the reference's stb_image
  * decoder is third-party code that is not re-created) or set from memory; .hdr files are read by an
  * own Radiance RGBE reader.
  */
@@ -34,7 +34,8 @@
 
 #include "vector.h"
 
-#define MAX_OCTREE_DEPTH 6          /* src/geometry.cuh:4 */
+#define MAX_OCTREE_DEPTH 6          /* src/geometry.cuh:4: the reference's fixed leaf depth, the default here */
+#define OCTREE_DEPTH_LIMIT 10       /* deepest octree the library builds (PT_MAX_OCTREE_DEPTH) */
 #define AABB_PADDING 0.0001f        /* src/geometry.cuh:7 */
 
 struct pt_scene;
@@ -155,7 +156,10 @@ public:
 
     void copy_to_device() {}                         /* uploaded with the scene */
     void free_from_device() {}
-    void construct_octree();
+    /* The reference fixes the leaf depth at compile time (MAX_OCTREE_DEPTH, src/geometry.cuh:4,
+     * src/entity.cu:167-170); here it is a run-time argument with that value as its default, so
+     * existing scene scripts compile unchanged and large meshes can ask for a deeper tree (1..10). */
+    void construct_octree(int depth = MAX_OCTREE_DEPTH);
     void scale(float factor);
     void translate(vec3 delta);
     void rotate(vec3 rot);
@@ -174,9 +178,15 @@ public:
     const AABB &bounds() const { return aabb; }
     vec3 get_center() const { return center; }
     float get_radius() const { return radius; }
-    bool wants_octree() const { return octree_requested; }
+    bool wants_octree() const { return requested_octree_depth > 0; }
+    int octree_depth() const { return requested_octree_depth; }     /* 0 = no octree requested */
+    /* builds the octree of the mesh as it is NOW on the host (nothing is uploaded) and reports its shape:
+     * nodes per depth (depth + 1 entries), leaf references and the largest leaf */
+    struct OctreeStatistics { std::vector<long long> nodes_per_depth; long long n_nodes = 0, n_leaf_refs = 0, max_leaf = 0; };
+    OctreeStatistics octree_statistics() const;
 
 private:
+    template <typename F> void transform_vertices(F f);
     Vertex *vertices = nullptr;
     Triangle *triangles = nullptr;
     vec2 *uvs = nullptr;
@@ -186,7 +196,7 @@ private:
     AABB aabb;
     float radius = 0.0f;
     vec3 center = vec3(0.0f);
-    bool octree_requested = false;
+    int requested_octree_depth = 0;
 };
 
 /* ------------------------------------------------------------------ scene */
@@ -208,6 +218,9 @@ public:
 
     pt_scene *device_scene() const { return handle; }   /* valid between copy_to_device and free_from_device */
     int device = 0;                                      /* GPU the scene is copied to */
+    /* builds this scene on `device` and returns the library handle; the caller owns it (pt_scene_destroy).
+     * copy_to_device() is build_on(this->device) kept in the scene object. */
+    pt_scene *build_on(int device) const;
 
 private:
     std::vector<float> hdri;
@@ -231,8 +244,14 @@ public:
     void set_samples_per_pixel(unsigned int spp);
     Image render(const Camera &camera, Scene &scene);
 
-    /* extensions: the RNG seed (the reference hard-codes 1337, src/renderer.cu:26), and the linear
-     * HDR image (un-normalised sample sums) of the last render for tooling */
+    /* extensions: the RNG seed (the reference hard-codes 1337, src/renderer.cu:26), the GPUs to render
+     * on, and the linear HDR image (un-normalised sample sums) of the last render for tooling.
+     * devices empty (default): the scene's own device, like the reference's single-GPU render
+     * (src/renderer.cu:209-216).  With several entries the scene is copied to every listed GPU, one host
+     * thread per GPU renders its share of the sample range (samples are drawn from the Philox stream
+     * (seed; pixel, sample), so the shares add up to the single-GPU image), the per-GPU sums are added on
+     * devices[0] in list order, and the post chain runs there. */
+    std::vector<int> devices;
     unsigned int seed = 1337;
     std::vector<vec3> last_hdr_sum;
     unsigned int last_samples_per_pixel = 0;
@@ -257,6 +276,9 @@ void apply_aces(std::vector<vec3> &buf);
 void image_add(std::vector<vec3> &buf, const std::vector<vec3> &layer, float opacity = 1.0f);
 std::vector<vec3> apply_threshold(const std::vector<vec3> &in_buf, float threshold);
 void apply_filter(std::vector<vec3> &buf, ivec2 resolution, const Kernel &kernel, FilterType filter_type = NORMAL);
+/* GPU on which the free post-processing functions above run (default 0; the reference always used device 0) */
+void set_post_processing_device(int device);
+int post_processing_device();
 
 /* ------------------------------------------------------------------ io */
 void save_ppm(const std::string &filepath, const Image &img);

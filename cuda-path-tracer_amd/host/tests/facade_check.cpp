@@ -6,7 +6,8 @@
  *   facade_check mesh  <in.obj> <out.bin> [ops]      ops: s<f>  t<x>,<y>,<z>  r<x>,<y>,<z>
  *   facade_check hdr   <in.hdr> <out.bin>
  *   facade_check pnm   <in.ppm|pgm> <channels> <out.bin>
- *   facade_check teapot <utah.obj> <floor.obj> <w> <h> <spp> <out.bin>      (needs a GPU)
+ *   facade_check teapot <utah.obj> <floor.obj> <w> <h> <spp> <out.bin> [octree depth [devices, e.g. 0,0]]   (needs a GPU)
+ *   facade_check octree <in.obj> <depth>                                     (prints the tree's shape)
  *   facade_check post  <w> <h> <out.bin>                                     (needs a GPU)
  */
 #include <cstdio>
@@ -77,7 +78,7 @@ static int cmd_pnm(char **argv) {
 }
 
 /* the teapot scene of the Python scene library, written against the class API */
-static int cmd_teapot(char **argv) {
+static int cmd_teapot(int argc, char **argv) {
     Material m_floor(vec3(0.8f, 0.8f, 0.8f), vec3(0.0f), 0, 0, false);
     Material m_pot(vec3(0.8f, 0.6f, 0.3f), vec3(0.3f, 0.3f, 0.3f), 0, 0.5f, true);
     Material m_light(vec3(1, 1, 1), vec3(0.0f), 10, 0, false);
@@ -86,7 +87,8 @@ static int cmd_teapot(char **argv) {
     Entity light(vec3(-150.0f, 160.0f, -40.0f), 40.0f, &m_light);
     floor.scale(20.0f);
     floor.translate(vec3(-205.3 - 27.5, -36.4, 82.5 - 28.5));
-    pot.construct_octree();
+    if (argc > 8) pot.construct_octree(atoi(argv[8]));
+    else pot.construct_octree();
     Scene scene;
     scene.add_entity(&pot);
     scene.add_entity(&floor);
@@ -96,6 +98,9 @@ static int cmd_teapot(char **argv) {
     camera.focal_length = 1.6f;
     Renderer renderer;
     renderer.set_samples_per_pixel((unsigned)atoi(argv[6]));
+    if (argc > 9)
+        for (const char *p = argv[9]; *p; p++)
+            if (*p != ',') renderer.devices.push_back(*p - '0');
     Image img = renderer.render(camera, scene);
     FILE *f = fopen(argv[7], "wb");
     const int32_t hdr[3] = {w, h, (int32_t)renderer.last_samples_per_pixel};
@@ -141,11 +146,23 @@ static int cmd_post(char **argv) {
     return 0;
 }
 
+static int cmd_octree(char **argv) {
+    Material m;
+    Entity e(argv[2], &m);
+    e.construct_octree(atoi(argv[3]));
+    const Entity::OctreeStatistics st = e.octree_statistics();
+    printf("depth %d nodes %lld leaf_refs %lld max_leaf %lld per_depth", e.octree_depth(), st.n_nodes, st.n_leaf_refs, st.max_leaf);
+    for (long long n : st.nodes_per_depth) printf(" %lld", n);
+    printf("\n");
+    return 0;
+}
+
 int main(int argc, char **argv) {
     if (argc >= 4 && !strcmp(argv[1], "mesh")) return cmd_mesh(argc, argv);
     if (argc == 4 && !strcmp(argv[1], "hdr")) return cmd_hdr(argv);
     if (argc == 5 && !strcmp(argv[1], "pnm")) return cmd_pnm(argv);
-    if (argc == 8 && !strcmp(argv[1], "teapot")) return cmd_teapot(argv);
+    if (argc >= 8 && argc <= 10 && !strcmp(argv[1], "teapot")) return cmd_teapot(argc, argv);
+    if (argc == 4 && !strcmp(argv[1], "octree")) return cmd_octree(argv);
     if (argc == 5 && !strcmp(argv[1], "post")) return cmd_post(argv);
     fprintf(stderr, "usage: see the header of facade_check.cpp\n");
     return 2;

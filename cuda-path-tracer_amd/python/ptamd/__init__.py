@@ -56,9 +56,9 @@ HIT_DTYPE = np.dtype([("entity", "<i4"), ("triangle", "<i4"), ("t", "<f4"), ("bu
 ABI_SYMBOLS = [
     "pt_last_error", "pt_device_count", "pt_device_name", "pt_scene_create", "pt_scene_destroy", "pt_scene_add_material",
     "pt_scene_add_mesh", "pt_scene_add_sphere", "pt_scene_set_hdri", "pt_scene_commit", "pt_scene_octree_info",
-    "pt_scene_octree_dump", "pt_scene_device_bytes", "pt_trace_rays", "pt_camera_rays", "pt_render_accumulate",
-    "pt_render_accumulate_noalloc", "pt_noalloc_max_partial_bytes", "pt_scene_set_launch", "pt_scene_get_launch",
-    "pt_scene_set_profiling", "pt_scene_schedule_counters", "pt_scene_last_render_kernel_ms", "pt_compound_buffers", "pt_apply_filter", "pt_make_gaussian", "pt_make_mean", "pt_normalize_image", "pt_apply_threshold",
+    "pt_scene_octree_dump", "pt_scene_device_bytes", "pt_trace_rays", "pt_camera_rays", "pt_sample_hdri", "pt_sample_material", "pt_box_intersects_triangle", "pt_render_accumulate",
+    "pt_render_accumulate_noalloc", "pt_noalloc_max_partial_bytes", "pt_scene_set_launch", "pt_scene_get_launch", "pt_scene_render_residency",
+    "pt_scene_set_profiling", "pt_scene_schedule_counters", "pt_scene_last_render_kernel_ms", "pt_compound_buffers", "pt_reduce_sum", "pt_apply_filter", "pt_make_gaussian", "pt_make_mean", "pt_normalize_image", "pt_apply_threshold",
     "pt_image_add", "pt_apply_aces", "pt_gamma_correct", "pt_post_chain", "pt_malloc", "pt_free", "pt_memset", "pt_upload",
     "pt_download", "pt_stream_synchronize",
 ]
@@ -89,16 +89,21 @@ def lib():
         L.pt_scene_device_bytes.argtypes = [vp] + [C.POINTER(C.c_uint64)] * 5
         L.pt_trace_rays.argtypes = [vp, vp, i64, vp, vp, i32, vp, vp]
         L.pt_camera_rays.argtypes = [i32, C.POINTER(Camera), u32, i32, vp, vp]
+        L.pt_sample_hdri.argtypes = [vp, vp, i64, vp]
+        L.pt_sample_material.argtypes = [vp, i32, vp, i64, vp, vp, vp, vp]
+        L.pt_box_intersects_triangle.argtypes = [vp, vp, vp, vp, vp, i32, C.POINTER(C.c_int)]
         L.pt_render_accumulate.argtypes = [vp, C.POINTER(Camera), u32, i32, i32, i32, vp, vp, vp]
         L.pt_render_accumulate_noalloc.argtypes = [vp, C.POINTER(Camera), u32, i32, i32, i32, vp, vp]
         L.pt_noalloc_max_partial_bytes.argtypes = []
         L.pt_noalloc_max_partial_bytes.restype = C.c_size_t
         L.pt_scene_set_launch.argtypes = [vp, i32, i32]
         L.pt_scene_get_launch.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        L.pt_scene_render_residency.argtypes = [vp, C.POINTER(C.c_int)]
         L.pt_scene_set_profiling.argtypes = [vp, i32]
         L.pt_scene_schedule_counters.argtypes = [vp, vp]
         L.pt_scene_last_render_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
         L.pt_compound_buffers.argtypes = [i32, vp, vp, i64, i32, vp]
+        L.pt_reduce_sum.argtypes = [i32, vp, i32, C.POINTER(C.c_int), C.POINTER(vp), i64]
         L.pt_apply_filter.argtypes = [i32, vp, vp, i32, i32, vp, i32, i32, vp]
         L.pt_make_gaussian.argtypes = [C.c_uint, f32, vp]
         L.pt_make_mean.argtypes = [C.c_uint, vp]
@@ -116,6 +121,28 @@ def lib():
         L.pt_stream_synchronize.argtypes = [i32, vp]
         _lib = L
     return _lib
+
+
+def source_hash():
+    """SHA-256 over the library's sources (csrc/ and the public header): identifies the kernel a profile or a
+    counter file was measured with.  Returns None when the sources are not next to the library."""
+    import hashlib
+
+    files = []
+    csrc = os.path.join(PKG_ROOT, "csrc")
+    hdr = os.path.join(os.path.dirname(PKG_ROOT), "include", "ptamd.h")
+    if not os.path.isdir(csrc) or not os.path.exists(hdr):
+        return None
+    for name in sorted(os.listdir(csrc)):
+        if name.endswith((".hip", ".h", ".cpp")) or name == "Makefile":
+            files.append(os.path.join(csrc, name))
+    files.append(hdr)
+    h = hashlib.sha256()
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()
 
 
 def check(rc):
@@ -274,6 +301,21 @@ class Scene:
     def trace_device(self, d_rays_ptr, n, d_hits_ptr, stream=None):
         check(self.L.pt_trace_rays(self.h, d_rays_ptr, n, d_hits_ptr, None, 0, None, stream))
 
+    def sample_hdri(self, dirs):
+        dirs = _f32(dirs).reshape(-1, 3)
+        out = np.zeros_like(dirs)
+        check(self.L.pt_sample_hdri(self.h, dirs.ctypes.data, len(dirs), out.ctypes.data))
+        return out
+
+    def sample_material(self, material, uv):
+        """-> albedo (n,3), specular (n,3), smoothness (n,), tangent-space normal (n,3)"""
+        uv = _f32(uv).reshape(-1, 2)
+        n = len(uv)
+        a, s, nn = np.zeros((n, 3), np.float32), np.zeros((n, 3), np.float32), np.zeros((n, 3), np.float32)
+        sm = np.zeros(n, np.float32)
+        check(self.L.pt_sample_material(self.h, material, uv.ctypes.data, n, a.ctypes.data, s.ctypes.data, sm.ctypes.data, nn.ctypes.data))
+        return a, s, sm, nn
+
     def render_accumulate(self, cam, seed, sample_begin, sample_end, n_split, d_split_ptr, want_counters=False, stream=None):
         cnt = Counters()
         check(self.L.pt_render_accumulate(self.h, C.byref(cam), seed, sample_begin, sample_end, n_split, d_split_ptr,
@@ -293,6 +335,12 @@ class Scene:
         kb, q = C.c_int(0), C.c_int(0)
         check(self.L.pt_scene_get_launch(self.h, C.byref(kb), C.byref(q)))
         return dict(kernel_build="heavy" if kb.value else "light", quorum=int(q.value))
+
+    def waves_per_simd(self):
+        """Workgroups of the render kernel resident per CU (= waves per SIMD the kernel was instantiated for)."""
+        n = C.c_int(0)
+        check(self.L.pt_scene_render_residency(self.h, C.byref(n)))
+        return int(n.value)
 
     def schedule_counters(self):
         out = (C.c_uint64 * 8)()
@@ -334,6 +382,13 @@ def camera_rays(cam, seed, sample, device=0):
     out = np.zeros((cam.res_x * cam.res_y, 6), dtype=np.float32)
     check(lib().pt_camera_rays(device, C.byref(cam), seed, sample, out.ctypes.data, None))
     return out
+
+
+def box_intersects_triangle(bmin, bmax, v0, v1, v2, pad_box=False):
+    a = [_f32(x) for x in (bmin, bmax, v0, v1, v2)]
+    out = C.c_int(0)
+    check(lib().pt_box_intersects_triangle(*[x.ctypes.data for x in a], int(pad_box), C.byref(out)))
+    return bool(out.value)
 
 
 def make_gaussian(size, sigma):

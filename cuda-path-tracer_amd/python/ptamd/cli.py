@@ -9,6 +9,7 @@ chunks, so a render can be checkpointed and resumed; with several ranks every ra
 of the sample range and rank 0 combines the sums (one RCCL sum-reduce) and writes the image.
 """
 import argparse
+import hashlib
 import os
 import sys
 import time
@@ -26,6 +27,10 @@ def main(argv=None):
     ap.add_argument("--checkpoint", default="", help="write the accumulation state here after every chunk (single GPU)")
     ap.add_argument("--resume", action="store_true", help="continue from --checkpoint if it exists")
     args = ap.parse_args(argv)
+    if args.chunk < 1:
+        ap.error("--chunk must be at least 1")
+    if args.spp < 0:
+        ap.error("--spp must not be negative")
 
     import ptamd
     from ptamd import dist as ptdist
@@ -49,21 +54,16 @@ def main(argv=None):
     spp = ptdist.effective_spp(args.spp if args.spp else settings["spp"])
     scene, cam = ptamd.scene_from_description(desc, device=local_rank)
     begin, end = ptdist.shard_samples(spp, rank, world)
-    acc = Accumulator(scene, cam, seed=settings["seed"], device=local_rank)
-    acc.samples_done = 0
-    first = begin
+    # a checkpoint is only valid for the scene file it was rendered from: its hash travels in the checkpoint
+    with open(args.scene, "rb") as f:
+        tag = "scene-sha256:" + hashlib.sha256(f.read()).hexdigest()
+    acc = Accumulator(scene, cam, seed=settings["seed"], device=local_rank, first_sample=begin, tag=tag)
     if args.resume and args.checkpoint and world == 1 and os.path.exists(args.checkpoint):
-        acc.load(args.checkpoint)
-        first = begin + acc.samples_done
+        acc.load(args.checkpoint, max_samples=end - begin)
         print(f"resumed at {acc.samples_done} samples per pixel", file=sys.stderr)
     t0 = time.time()
-    # the accumulator counts from 0; this rank's samples start at `begin`
-    done = first - begin
-    while begin + done < end:
-        n = min(args.chunk, end - begin - done)
-        scene.render_accumulate(cam, settings["seed"], begin + done, begin + done + n, acc.n_split, acc.split.ptr, False, None)
-        done += n
-        acc.samples_done = done
+    while acc.samples_done < end - begin:
+        acc.add(min(args.chunk, end - begin - acc.samples_done))
         if args.checkpoint and world == 1:
             acc.save(args.checkpoint)
     total = acc.radiance_sum()

@@ -142,6 +142,21 @@ int pt_trace_rays(pt_scene *scene, const float *rays, int64_t n, pt_hit *hits, i
 int pt_camera_rays(int device, const pt_camera *camera, uint32_t seed, int sample, float *rays,
                    void *stream);
 
+/* ---- parity queries of single hot-path functions (for tooling and tests; host pointers, blocking).
+ * pt_sample_hdri: Scene::sample_hdri (src/scene.cuh:36-82) of the committed scene for n directions
+ * (n x 3 floats) -> n x 3 floats, exactly the lookup the render kernel performs for escaped paths.
+ * pt_sample_material: Material::sample_albedo / sample_specular / sample_smoothness / sample_normal
+ * (src/material.cuh:21-44, src/texture.cuh:22-43) of one material for n (u, v) pairs; texel indices
+ * are clamped into the texture where the reference reads past it (u = 1 or v = 0).
+ * pt_box_intersects_triangle: AABB::intersects_triangle (src/aabb.cu:64-120), the SAT test the octree
+ * builder inserts triangles with; pad_box != 0 pads the box by AABB_PADDING first like the AABB(min, max)
+ * constructor (src/geometry.cuh:81-84).  Host only. */
+int pt_sample_hdri(pt_scene *scene, const float *dirs, int64_t n, float *rgb_out);
+int pt_sample_material(pt_scene *scene, int material, const float *uv, int64_t n, float *albedo,
+                       float *specular, float *smoothness, float *normal);
+int pt_box_intersects_triangle(const float bmin[3], const float bmax[3], const float v0[3],
+                               const float v1[3], const float v2[3], int pad_box, int *overlaps);
+
 /* ---- render: replaces render_init + device_render (src/renderer.cu:19-51, 233-257).
  * Adds, for every pixel, the radiance samples sample_begin..sample_end-1 into n_split split
  * buffers: d_split is a DEVICE pointer to n_split x H x W x 3 floats (src/renderer.cu:194-197);
@@ -184,6 +199,10 @@ size_t pt_noalloc_max_partial_bytes(void);
  * the current ones (outputs may be NULL). */
 int pt_scene_set_launch(pt_scene *scene, int kernel_build, int quorum);
 int pt_scene_get_launch(pt_scene *scene, int *kernel_build, int *quorum);
+/* 256-thread workgroups of the render kernel resident per CU for the committed scene = waves per SIMD =
+ * the register budget the kernel was instantiated for: the heavy build runs 5 (96 registers), or 4 (128) /
+ * 3 (168) when the LDS stacks of a deep octree (depth 7-8 / 9-10) leave room for no more; the light build 4. */
+int pt_scene_render_residency(pt_scene *scene, int *workgroups_per_cu);
 /* Measurement aid (no counterpart in the reference): when enabled, every pt_render_accumulate
  * brackets its path-tracing kernel with two HIP events on the launch stream;
  * pt_scene_last_render_kernel_ms waits for the last launch and returns its duration. */
@@ -195,6 +214,15 @@ int pt_scene_last_render_kernel_ms(pt_scene *scene, float *ms);
 /* d_out[p] = sum_z d_split[z][p]  (compound_buffers, src/post_processing.cu:243-256); device ptrs */
 int pt_compound_buffers(int device, const float *d_split, float *d_out, int64_t n_pixels,
                         int n_split, void *stream);
+
+/* ---- multi-GPU inside one process (no counterpart in the reference, which renders on device 0 only,
+ * src/renderer.cu:209-216): d_dst (on dst_device) += d_src[0] + d_src[1] + ... in THAT order, each n_floats
+ * floats on device src_devices[i].  Sources reach dst_device by peer copies (xGMI between peers) into a
+ * staging buffer and are added one after the other, so the result does not depend on timing.  Blocking: all
+ * work on the source buffers must have completed before the call; the sum is complete when it returns.
+ * One process per GPU setups use a collective instead (torch.distributed / RCCL reduce, see bench.py). */
+int pt_reduce_sum(int dst_device, float *d_dst, int n_src, const int *src_devices,
+                  const float *const *d_src, int64_t n_floats);
 
 /* ---- post-processing: replaces apply_filter/device_apply_filter and the CPU loops
  *      (src/post_processing.cu:105-187, 194-278).  All image pointers are DEVICE pointers. */

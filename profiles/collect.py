@@ -2,10 +2,11 @@
 """Copies the judged files of one profiling run from gpurun_out/ into profiles/<round>/.
 
 usage: profiles/collect.py <tag> <round-dir>      e.g.  profiles/collect.py r1j profiles/r1
-Expects gpurun_out/prof_<tag>/ (profiles/run_profile.sh with FULL_TRAFFIC=1), gpurun_out/bench_default_<tag>.json and,
+Expects gpurun_out/prof_<tag>/ (profiles/run_profile.sh), gpurun_out/bench_default_<tag>.json and,
 optionally, gpurun_out/cfg_<workload>.json for the five configurations.  Writes kernel_stats_<tag>.csv, bench_line_<tag>.json,
 bench_default_<tag>.json, summary_<tag>.json, configs_<tag>.json and refreshes traffic.json / pmc_ratios.json (the two files
-bench.py reads)."""
+bench.py reads), both stamped with the SHA-256 of the library sources the profiled run reported in its bench line
+(`library_source_hash`).  bench.py drops the two files when the stamp no longer matches the sources it runs with."""
 import collections
 import csv
 import glob
@@ -17,6 +18,7 @@ import sys
 
 tag, out = sys.argv[1], sys.argv[2]
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+os.makedirs(out, exist_ok=True)
 prof = os.path.join(root, "gpurun_out", f"prof_{tag}")
 
 
@@ -35,6 +37,7 @@ with open(f"{out}/summary_{tag}.json", "w") as f:
 
 bench = json.load(open(f"{out}/bench_line_{tag}.json"))
 workload = bench["config"]["workload"]
+source_hash = bench["library_source_hash"]
 
 
 def timed_kernel_counters(passes):
@@ -48,25 +51,35 @@ def timed_kernel_counters(passes):
     return acc, name
 
 
-full, kname = timed_kernel_counters(["full_fetch", "full_write"])
-traffic = int(full["FETCH_SIZE"] * 1024 * 2 + full["WRITE_SIZE"] * 1024)
+def dispatches(pass_name):
+    """number of dispatches of the timed kernel in one pass (the counter sums are divided by it)"""
+    ids = set()
+    for r in csv.DictReader(open(newest(f"{prof}/pmc_{pass_name}/*/*counter_collection.csv"))):
+        if "render_kernel<false" in r["Kernel_Name"]:
+            ids.add(r.get("Dispatch_Id"))
+    return max(len(ids), 1)
+
+
+full, kname = timed_kernel_counters(["tcc1", "tcc2"])
+fetch_kb, write_kb = full["FETCH_SIZE"] / dispatches("tcc1"), full["WRITE_SIZE"] / dispatches("tcc2")
+traffic = int(fetch_kb * 1024 * 2 + write_kb * 1024)
 json.dump({
-    "workload": workload, "kernel": kname,
-    "source": f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over `python3 bench.py --no-cpu-baseline --steps 1 "
-              f"--warmup 0`, profiles/run_profile.sh {tag} with FULL_TRAFFIC=1",
-    "FETCH_SIZE_KB": full["FETCH_SIZE"], "WRITE_SIZE_KB": full["WRITE_SIZE"],
+    "workload": workload, "kernel": kname, "source_hash": source_hash,
+    "source": f"rocprofv3 --pmc FETCH_SIZE TCC_HIT_sum / --pmc WRITE_SIZE TCC_MISS_sum TCC_REQ_sum (separate passes) over `python3 bench.py "
+              f"--no-cpu-baseline --steps 1 --warmup 0`, profiles/run_profile.sh {tag}; per dispatch of the timed kernel",
+    "FETCH_SIZE_KB": fetch_kb, "WRITE_SIZE_KB": write_kb,
     "correction": "FETCH_SIZE x2 on gfx950 (128-byte requests tallied as 64 bytes); calibrated for streaming reads, this kernel "
                   "gathers: treat as +-2x",
-    "note": "the image is 25 MB per slice: nearly all of the writes, and as much of the reads, are register spills of the "
-            "many-waves build around the shading code",
     "traffic_bytes_per_launch": traffic}, open(f"{out}/traffic.json", "w"), indent=1)
 
 acc, kname = timed_kernel_counters(["sq1", "sq2", "tcc1", "tcc2", "tcp"])
 g = acc["GRBM_GUI_ACTIVE"] / 8
 json.dump({
-    "workload": workload, "kernel": kname,
-    "source": f"rocprofv3 --pmc passes of profiles/run_profile.sh {tag} (256-spp launch of the same scene), counters of the timed "
-              "kernel only",
+    "workload": workload, "kernel": kname, "source_hash": source_hash,
+    "source": f"rocprofv3 --pmc passes of profiles/run_profile.sh {tag} (the benchmark's own launch: same scene, full sample count), "
+              "counters of the timed kernel only",
+    "valu_instructions_per_cycle_per_simd": round(acc["SQ_INSTS_VALU"] / (1024 * g), 4),
+    "dispatches_per_pass": dispatches("sq1"),
     "valu_busy": round(acc["SQ_ACTIVE_INST_VALU"] * 4 / (1024 * g), 3),
     "active_lanes_per_valu_instruction": round(acc["SQ_THREAD_CYCLES_VALU"] / (64 * acc["SQ_ACTIVE_INST_VALU"]), 3),
     "wait_for_issue_over_wave_cycles": round(acc["SQ_WAIT_INST_ANY"] / acc["SQ_WAVE_CYCLES"], 3),

@@ -10,9 +10,9 @@ out=$root/gpurun_out/prof_$tag
 mkdir -p $out
 cd $root
 # the kernel-trace pass runs the benchmark's default command line, so its per-kernel average is
-# directly comparable with the HIP-event time in the bench line; the counter passes use a shorter
-# run of the same workload (PMC_ARGS, default 256 spp, one step)
-args="--no-cpu-baseline ${PMC_ARGS:---spp 256 --steps 1 --warmup 0}"
+# directly comparable with the HIP-event time in the bench line; the counter passes run the same
+# workload at its full sample count (the launch the bench times), one timed step (PMC_ARGS overrides)
+args="--no-cpu-baseline ${PMC_ARGS:---steps 1 --warmup 0}"
 timeout -s KILL 400 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python3 bench.py $* > $out/trace_bench.json 2> $out/trace.err || { echo "trace pass failed"; tail -5 $out/trace.err; exit 1; }
 pass() {
   name=$1; shift
@@ -21,14 +21,7 @@ pass() {
 pass sq1 SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_INSTS_SALU SQ_WAIT_INST_ANY
 pass sq2 SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_SMEM
 pass tcc1 FETCH_SIZE TCC_HIT_sum
-# memory-side traffic of the benchmark's own default launch (for roofline.traffic): FETCH_SIZE and WRITE_SIZE
-# cannot share a pass
-if [ -n "$FULL_TRAFFIC" ]; then
-  args="--no-cpu-baseline --steps 1 --warmup 0"
-  pass full_fetch FETCH_SIZE
-  pass full_write WRITE_SIZE
-  args="--no-cpu-baseline ${PMC_ARGS:---spp 256 --steps 1 --warmup 0}"
-fi
+# (memory-side traffic for roofline.traffic: FETCH_SIZE of pass tcc1 and WRITE_SIZE of pass tcc2 -- they cannot share a pass)
 pass tcc2 WRITE_SIZE TCC_MISS_sum TCC_REQ_sum
 pass tcp TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum GRBM_GUI_ACTIVE
 echo "profile passes done: $out"

@@ -175,6 +175,54 @@ def test_renderer_render_matches_binding(pt, scenes, tmp_path):
     assert ppm.startswith(b"P6\n") and len(ppm.split(b"255\n", 1)[1]) == w * h * 3
 
 
+def test_runtime_octree_depth_through_the_class_api(pt):
+    """Entity::construct_octree(depth): the default is the reference's fixed depth 6 (known node counts of the
+    teapot), any depth up to 10 is accepted, and the tree equals the one the binding builds."""
+    r = _run("octree", TEAPOT, 6)
+    assert r.returncode == 0, r.stderr
+    assert r.stdout.split() == "depth 6 nodes 24734 leaf_refs 47874 max_leaf 32 per_depth 1 8 52 226 988 4289 19170".split()
+    r = _run("octree", TEAPOT, 9)
+    assert r.returncode == 0, r.stderr
+    from ptamd import scenes as S
+
+    pos, tri, _, _ = S.load_obj(TEAPOT)
+    sc = pt.Scene(-1)
+    info = sc.octree_info(sc.add_mesh(pos, tri, sc.add_material(), octree_depth=9))
+    words = r.stdout.split()
+    assert int(words[1]) == 9 and int(words[3]) == info["n_nodes"] and int(words[5]) == info["n_leaf_refs"]
+    assert [int(x) for x in words[9:]] == info["nodes_per_depth"].tolist()
+    r = _run("octree", TEAPOT, 11)
+    assert r.returncode != 0 and "depth must be in" in r.stderr
+
+
+@pytest.mark.gpu
+def test_renderer_depth_nine_and_two_device_render(pt, scenes, tmp_path):
+    """Renderer::render with an octree of depth 9 requested through the class API, on one GPU and as a
+    two-"device" render (both entries name GPU 0: two host threads, two scene copies, two sample shares,
+    peer-copy sum): the radiance sums equal the binding's render of the same scene at depth 9 (bit-exact on
+    one device; equal up to the association of the two shares' sums on two)."""
+    w, h, spp = 128, 72, 64
+    desc = scenes.teapot_scene(res=(w, h), octree_depth=9)
+    sc, cam = pt.scene_from_description(desc)
+    want = pt.render_image(sc, cam, spp, seed=1337, n_split=4)
+    lo = pt.render_image(sc, cam, spp // 2, seed=1337, n_split=4)
+    hi = pt.render_image(sc, cam, spp // 2, seed=1337, n_split=4, sample_begin=spp // 2)
+    sc.close()
+    n = w * h * 3
+    for devices, expect in ((None, want), ("0,0", lo + hi)):
+        out = tmp_path / "r.bin"
+        args = ["teapot", TEAPOT, FLOOR, w, h, spp, out, 9] + ([devices] if devices else [])
+        r = _run(*args)
+        assert r.returncode == 0, r.stdout + r.stderr
+        raw = open(out, "rb").read()
+        hdr_sum = np.frombuffer(raw, np.float32, n, 12).reshape(h, w, 3)
+        ldr = np.frombuffer(raw, np.float32, n, 12 + 4 * n).reshape(h, w, 3)
+        assert np.array_equal(hdr_sum, expect), devices
+        assert np.array_equal(ldr, pt.post_chain_host(expect, spp)), devices
+        if devices:
+            assert r.stdout.count("Device 0") == 2
+
+
 @pytest.mark.gpu
 def test_post_functions_match_fused_chain(pt, tmp_path):
     """normalize / threshold / gaussian bloom / add / ACES / gamma / bilateral called one by one through

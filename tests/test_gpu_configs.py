@@ -1,0 +1,160 @@
+"""GPU parity of the benchmark configurations whose kernel instantiations the small scenes never select.
+
+The render kernel's heavy build (cooperative leaf phase) is instantiated for 5, 4 and 3 waves per SIMD; which
+one runs follows from the scene (>= 64 k triangle pairs -> heavy) and the octree depth (LDS stacks: depth <= 6
+-> 5 waves, 7-8 -> 4, 9-10 -> 3).  Every case here builds a scene large enough that pt_scene_commit picks the
+heavy build BY ITSELF, checks which instantiation runs, and compares with the CPU oracle:
+  * pt_trace_rays on camera rays and on secondary rays leaving the first hits: entity / triangle / t /
+    barycentrics / uv / position / normal bit-exact, triangle-test order and work counters identical;
+  * the render: the criteria of tests/parity.py (per-pixel agreement, RMSE against the Monte-Carlo noise,
+    counters within 0.5 %).
+The scenes are the procedural stand-ins of the benchmark configurations (the reference's dragon.obj, 80k.obj
+and HDRI are not shipped) at reduced triangle counts and frame sizes, so that the oracle finishes in seconds;
+the full-size runs at the end check size-independent properties only.
+"""
+import numpy as np
+import pytest
+
+from parity import assert_render_parity
+
+pytestmark = pytest.mark.gpu
+
+
+def _bits(a):
+    return np.ascontiguousarray(a).view(np.uint32)
+
+
+def _secondary_rays(hits, rays, rng):
+    """Rays leaving the hit points the way color() continues a path (src/renderer.cu:126-136): origin =
+    position + 0.001 * normal, direction = a random unit vector flipped into the normal's hemisphere."""
+    m = hits["entity"] >= 0
+    pos, nrm = hits["position"][m], hits["normal"][m]
+    d = rng.normal(size=pos.shape).astype(np.float32)
+    d /= np.linalg.norm(d, axis=1, keepdims=True).astype(np.float32)
+    flip = (np.einsum("ij,ij->i", d, nrm) < 0)[:, None]
+    d = np.where(flip, -d, d).astype(np.float32)
+    o = (pos + np.float32(0.001) * nrm).astype(np.float32)
+    return np.ascontiguousarray(np.concatenate([o, d], axis=1), dtype=np.float32)
+
+
+def _check_trace(g, c, rays, stride):
+    hg, lg, cg = g.trace(rays, log_stride=stride)          # lane-by-lane leaf path, with the test log
+    hc, lc, cc = c.trace(rays, log_stride=stride)
+    hq, _, cq = g.trace(rays, log_stride=0)                # cooperative leaf phase
+    for h, cnt in ((hg, cg), (hq, cq)):
+        assert np.array_equal(h["entity"], hc["entity"])
+        assert np.array_equal(h["triangle"], hc["triangle"])
+        for f in ("t", "bu", "bv", "u", "v", "position", "normal"):
+            assert np.array_equal(_bits(h[f]), _bits(hc[f])), f
+        for k in ("segments", "aabb_tests", "node_visits", "tri_tests"):
+            assert cnt[k] == cc[k], k
+    assert np.array_equal(lg, lc), "triangle-test order differs"
+    return hc
+
+
+def _check_render(pt, g, cam_g, c, cam_c, res, spp):
+    img_g, cnt_g = pt.render_image(g, cam_g, spp, seed=1337, n_split=4, want_counters=True)
+    img_c, cnt_c = c.render(cam_c, 1337, 0, spp, n_threads=8)
+    conv, _ = c.render(cam_c, 1337, 1000, 1000 + 16 * spp, n_threads=8)
+    assert_render_parity(img_g / spp, img_c / spp, conv / (16 * spp), cnt_g, cnt_c, res[0] * res[1] * spp)
+
+
+CASES = {
+    # name: (builder kwargs, waves per SIMD the heavy build must be instantiated for, quorum picked at commit)
+    "hcandersen-5wave": (dict(kind="hcandersen", n_tris=60000, octree_depth=6, tex_res=256, hdri_res=(512, 256)), 5, 48),
+    "dragon-4wave": (dict(kind="dragon", n_tris=140000, octree_depth=7, hdri_res=(512, 256)), 4, 40),
+    "synthetic-3wave": (dict(kind="synthetic", n_tris=80000, octree_depth=9, hdri_res=(512, 256)), 3, 40),
+}
+
+
+def _build(scenes, spec, res):
+    spec = dict(spec)
+    kind = spec.pop("kind")
+    return dict(hcandersen=scenes.hcandersen_scene, dragon=scenes.dragon_scene, synthetic=scenes.synthetic_scene)[kind](res=res, **spec)
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_heavy_instantiations_match_oracle(pt, oracle, scenes, name, monkeypatch):
+    for var in ("PTAMD_KERNEL", "PTAMD_QUORUM", "PTAMD_LEAF_QUOTA"):
+        monkeypatch.delenv(var, raising=False)
+    spec, waves, quorum = CASES[name]
+    res = (96, 54)
+    desc = _build(scenes, spec, res)
+    g, cam_g = pt.scene_from_description(desc)
+    c, cam_c = oracle.scene_from_description(desc)
+    # commit chose the build the full-size benchmark configuration runs with
+    assert g.launch() == dict(kernel_build="heavy", quorum=quorum)
+    assert g.waves_per_simd() == waves
+    rng = np.random.default_rng(2024)
+    primary = np.concatenate([oracle.camera_rays(cam_c, 1337, s) for s in (0, 1, 2)], axis=0)
+    hc = _check_trace(g, c, primary, 96)
+    assert (hc["entity"] >= 0).mean() > 0.1
+    secondary = _secondary_rays(hc, primary, rng)
+    hs = _check_trace(g, c, secondary, 96)
+    tertiary = _secondary_rays(hs, secondary, rng)
+    if len(tertiary):
+        _check_trace(g, c, tertiary, 96)
+    _check_render(pt, g, cam_g, c, cam_c, res, 32)
+    if name == "synthetic-3wave":
+        # configuration 5 ends with the 5x5 bilateral filter on the tone-mapped image: whole post chain vs oracle
+        img_sum = pt.render_image(g, cam_g, 32, seed=1337)
+        got = pt.post_chain_host(img_sum, 32)
+        want = oracle.post_chain(img_sum, 32, res)
+        assert np.abs(got - want).max() <= 2e-5
+        taps = pt.make_gaussian(2, 0.7)
+        ldr = np.clip(img_sum / 32, 0, 1).astype(np.float32)
+        assert np.abs(pt.apply_filter_host(ldr, taps, bilateral=True) - oracle.apply_filter(ldr, taps, True)).max() <= 1e-5
+    g.close()
+
+
+def test_light_and_heavy_agree_on_the_large_scenes(pt, scenes, monkeypatch):
+    """The same three scenes through the light build (lane-by-lane leaves): identical image bits and counters."""
+    for name, (spec, waves, quorum) in CASES.items():
+        desc = _build(scenes, spec, (64, 40))
+        out = {}
+        for build in ("heavy", "light"):
+            monkeypatch.setenv("PTAMD_KERNEL", build)
+            g, cam = pt.scene_from_description(desc)
+            assert g.launch()["kernel_build"] == build
+            out[build] = pt.render_image(g, cam, 16, seed=5, want_counters=True)
+            g.close()
+        assert np.array_equal(_bits(out["heavy"][0]), _bits(out["light"][0])), name
+        assert out["heavy"][1] == out["light"][1], name
+
+
+def _full_size_properties(pt, scenes, workload, spp_full, spp_repeat):
+    cfg = scenes.CONFIGS[workload]
+    res = cfg["res"]
+    desc = cfg["builder"](res=res)
+    g, cam = pt.scene_from_description(desc)
+    n_pixels = res[0] * res[1]
+    img, cnt = pt.render_image(g, cam, spp_full, seed=1337, want_counters=True)
+    assert cnt["paths"] == n_pixels * spp_full
+    assert cnt["segments"] >= cnt["paths"] and cnt["segments"] <= 6 * cnt["paths"]
+    assert cnt["env_lookups"] <= cnt["paths"]
+    assert np.isfinite(img).all() and (img >= 0).all() and img.sum() > 0
+    a = pt.render_image(g, cam, spp_repeat, seed=3)
+    b = pt.render_image(g, cam, spp_repeat, seed=3)
+    assert np.array_equal(_bits(a), _bits(b))
+    launch, waves = g.launch(), g.waves_per_simd()
+    g.close()
+    return desc, launch, waves
+
+
+@pytest.mark.timeout(300)
+def test_full_size_dragon_configuration(pt, scenes, monkeypatch):
+    """Configuration 3 at its nominal size (871 k triangles, depth 7, 1920x1080, 1024 spp)."""
+    for var in ("PTAMD_KERNEL", "PTAMD_QUORUM", "PTAMD_LEAF_QUOTA"):
+        monkeypatch.delenv(var, raising=False)
+    desc, launch, waves = _full_size_properties(pt, scenes, "dragon", 1024, 64)
+    assert desc["n_tris"] > 850000 and launch["kernel_build"] == "heavy" and waves == 4
+
+
+@pytest.mark.timeout(600)
+def test_full_size_synthetic_configuration(pt, scenes, monkeypatch):
+    """Configuration 5 at its nominal size (20 M triangles, depth 9, 3840x2160): the full 4096 spp once
+    (path count, finiteness), bit-reproducibility on two 64-spp renders."""
+    for var in ("PTAMD_KERNEL", "PTAMD_QUORUM", "PTAMD_LEAF_QUOTA"):
+        monkeypatch.delenv(var, raising=False)
+    desc, launch, waves = _full_size_properties(pt, scenes, "synthetic", 4096, 64)
+    assert desc["n_tris"] > 19_000_000 and launch["kernel_build"] == "heavy" and waves == 3

@@ -38,3 +38,29 @@ def test_two_rank_gpu_render_equals_single(pt, scenes, tmp_path):
     # the same sample set; only the association of the last sums differs
     assert np.allclose(got, want, rtol=2e-5, atol=1e-5)
     assert not np.allclose(got, half, rtol=1e-3)
+
+
+def test_bench_two_ranks_on_one_gpu(tmp_path):
+    """bench.py's N > 1 path end to end -- rank start-up without a launcher, process group, sample sharding, the
+    sum-reduce, the max-over-ranks timer and counter all-reduces, the rank-0 JSON line -- with two ranks
+    sharing the one GPU of the test box over gloo (on a multi-GPU node the same code runs over RCCL)."""
+    import json
+
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    cmd = [sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--backend", "gloo", "--workload", "teapot", "--res", "96x56",
+           "--spp", "64", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["scaling"] == "strong" and d["backend"] == "gloo"
+    assert d["config"]["samples_per_rank"] == 32 and d["config"]["spp"] == 64
+    assert d["counters"]["paths"] == 96 * 56 * 64          # both ranks' counters, summed
+    assert d["value"] > 0 and d["ms_per_step"] > 0
+    assert d["roofline"]["bound"] == "valu-issue" and d["roofline"]["kernel_ms"] > 0
+    one = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--workload", "teapot", "--res", "96x56", "--spp", "64",
+                          "--steps", "1", "--warmup", "0", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=300)
+    assert one.returncode == 0, one.stderr[-2000:]
+    d1 = json.loads([ln for ln in one.stdout.splitlines() if ln.startswith("{")][0])
+    assert d1["n_gpus"] == 1 and d1["counters"] == d["counters"]

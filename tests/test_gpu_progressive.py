@@ -8,6 +8,7 @@ import numpy as np
 import pytest
 
 from conftest import REPO
+from parity import assert_render_parity
 from test_scenefile import _teapot_doc
 
 pytestmark = pytest.mark.gpu
@@ -66,3 +67,77 @@ def test_cli_renders_scene_file(pt, scenes, tmp_path):
                         "--checkpoint", str(ck), "--resume"], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "resumed at 64" in r.stderr
     assert open(tmp_path / "o2.ppm", "rb").read() == data
+
+
+def _assert_matches_oracle(img, c, cam_c, spp):
+    """img: normalised radiance of `spp` samples per pixel from the HIP path, against the oracle's render of
+    the same samples (criteria: tests/parity.py)."""
+    ref, _ = c.render(cam_c, 1337, 0, spp, n_threads=8)
+    conv, _ = c.render(cam_c, 1337, 1000, 1000 + 16 * spp, n_threads=8)
+    assert_render_parity(img, ref / spp, conv / (16 * spp))
+
+
+def test_chunked_and_resumed_accumulation_matches_oracle(pt, oracle, scenes, tmp_path):
+    """64 samples per pixel added as 24 + (checkpoint, new accumulator, resume) 8 + 32: the radiance the
+    accumulator reports is the oracle's render of samples 0..63."""
+    from ptamd.progressive import Accumulator
+
+    desc = scenes.teapot_scene(res=(96, 54))
+    sc, cam = pt.scene_from_description(desc)
+    c, cam_c = oracle.scene_from_description(desc)
+    first = Accumulator(sc, cam, seed=1337, tag="t")
+    first.add(24)
+    ck = str(tmp_path / "state")                     # no .npz suffix: written to exactly this path
+    first.save(ck)
+    assert os.path.exists(ck) and not os.path.exists(ck + ".npz")
+    first.close()
+    acc = Accumulator(sc, cam, seed=1337, tag="t")
+    acc.load(ck, max_samples=64)
+    assert acc.samples_done == 24
+    acc.add(8)
+    acc.add(32)
+    assert acc.samples_done == 64
+    _assert_matches_oracle(acc.radiance_sum() / 64, c, cam_c, 64)
+    with pytest.raises(ValueError, match="more than"):
+        Accumulator(sc, cam, seed=1337, tag="t").load(ck, max_samples=16)
+    with pytest.raises(ValueError, match="another scene"):
+        Accumulator(sc, cam, seed=1337, tag="other").load(ck)
+    with pytest.raises(ValueError, match="another sample index"):
+        Accumulator(sc, cam, seed=1337, tag="t", first_sample=32).load(ck)
+    # a shard that starts at sample 32 renders samples 32..63: first half + second half = the whole
+    lo = Accumulator(sc, cam, seed=1337)
+    lo.add(32)
+    hi = Accumulator(sc, cam, seed=1337, first_sample=32)
+    hi.add(32)
+    whole = pt.render_image(sc, cam, 64, seed=1337)
+    assert np.allclose(lo.radiance_sum() + hi.radiance_sum(), whole, rtol=2e-5, atol=1e-5)
+    sc.close()
+
+
+def test_cli_hdr_output_matches_oracle(pt, oracle, tmp_path):
+    """The command-line renderer's linear HDR output (PFM) of a scene file against the oracle's render of
+    the same scene description at equal spp; bad arguments are rejected instead of looping."""
+    from ptamd import io as ptio
+    from ptamd import scenefile as sf
+
+    path = tmp_path / "teapot.json"
+    path.write_text(json.dumps(_teapot_doc(tmp_path, res=(96, 54))))
+    env = dict(os.environ, PYTHONPATH=os.path.join(REPO, "cuda-path-tracer_amd", "python"))
+    hdr, ck = tmp_path / "o.pfm", tmp_path / "ck.npz"
+    base = [sys.executable, "-m", "ptamd.cli", str(path), "--out", str(tmp_path / "o.ppm"), "--hdr-out", str(hdr)]
+    r = subprocess.run(base + ["--chunk", "24", "--checkpoint", str(ck)], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    desc, settings = sf.load_scene(str(path))
+    assert settings["spp"] == 64
+    c, cam_c = oracle.scene_from_description(desc)
+    _assert_matches_oracle(ptio.load_pfm(str(hdr)), c, cam_c, 64)
+    r = subprocess.run(base + ["--chunk", "0"], env=env, capture_output=True, text=True, timeout=60)
+    assert r.returncode != 0 and "--chunk" in r.stderr
+    # a checkpoint of 64 samples cannot seed a 32-spp render, nor a render of an edited scene file
+    r = subprocess.run(base + ["--spp", "32", "--checkpoint", str(ck), "--resume"], env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and "more than" in r.stderr
+    doc = _teapot_doc(tmp_path, res=(96, 54))
+    doc["camera"]["focal_length"] = 1.7
+    path.write_text(json.dumps(doc))
+    r = subprocess.run(base + ["--checkpoint", str(ck), "--resume"], env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and "another scene" in r.stderr

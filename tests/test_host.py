@@ -89,6 +89,21 @@ def test_gaussian_tables_match_oracle(pt, oracle):
     assert np.array_equal(pt.make_mean(3), oracle.make_mean(3))
 
 
+def test_sat_and_tap_tables_match_the_committed_vectors(pt):
+    """The library's host-side SAT test (what its octree builder inserts triangles with) and tap tables
+    against the committed single-function vectors."""
+    from conftest import GOLDEN
+
+    t0 = np.load(os.path.join(GOLDEN, "t0_vectors.npz"))
+    for i in range(len(t0["sat_bmin"])):
+        for pad in (0, 1):
+            got = pt.box_intersects_triangle(t0["sat_bmin"][i], t0["sat_bmax"][i], *t0["sat_tri"][i], pad_box=bool(pad))
+            assert got == bool(t0["sat_result"][i, pad]), (i, pad)
+    for size, sigma, key in ((2, 0.7, "gauss_2_0p7"), (32, 10.0, "gauss_32_10"), (1, 3.0, "gauss_1_3")):
+        np.testing.assert_allclose(pt.make_gaussian(size, sigma), t0[key], rtol=1e-6, atol=0)
+    assert np.array_equal(pt.make_mean(3), t0["mean_3"])
+
+
 def test_shard_samples_partition():
     from ptamd import dist
 

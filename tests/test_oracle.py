@@ -187,3 +187,48 @@ def test_post_ops(oracle):
     split = rng.random((4, 6, 3), dtype=np.float32)
     assert np.allclose(oracle.compound_buffers(split, 4), split.sum(0), atol=1e-6)
     assert oracle.to_ppm_bytes(np.array([[[0.0, 0.5, 2.0]]], np.float32)).ravel().tolist() == [0, 127, 254]
+
+
+@pytest.fixture(scope="module")
+def t0():
+    return np.load(os.path.join(GOLDEN, "t0_vectors.npz"))
+
+
+def test_t0_vectors_sat_hdri_texels_tables_tonemap(oracle, t0):
+    """The oracle built HERE (this compiler, this libm) against the committed single-function vectors:
+    integer / boolean / copy results bit-exact, results that pass through acosf / powf / expf to 1e-6."""
+    n = len(t0["sat_bmin"])
+    for i in range(n):
+        for pad in (0, 1):
+            got = oracle.aabb_intersects_triangle(t0["sat_bmin"][i], t0["sat_bmax"][i], *t0["sat_tri"][i], pad_box=bool(pad))
+            assert got == bool(t0["sat_result"][i, pad]), (i, pad)
+    assert 0.2 < t0["sat_result"].mean() < 0.8
+    for k, (exposure, contrast, rot, smooth) in enumerate(t0["hdri_configs"].tolist()):
+        sc = oracle.OracleScene()
+        sc.set_hdri(t0["hdri_image"], exposure=exposure, contrast=contrast, rot=rot, smooth=bool(smooth))
+        np.testing.assert_allclose(sc.sample_hdri(t0[f"hdri_dirs{k}"]), t0[f"hdri_rgb{k}"], rtol=2e-6, atol=1e-6)
+    sc = oracle.OracleScene()
+    m_tex = sc.add_material((0.8, 0.8, 0.8), (0.2, 0.2, 0.2), 0.0, 0.5, False)
+    for which in ("albedo", "specular", "normal", "smoothness"):
+        sc.set_map(m_tex, which, t0["map_" + which])
+    m_plain = sc.add_material((0.3, 0.5, 0.7), (0.1, 0.2, 0.3), 0.0, 0.25, False)
+    for name, mid in (("tex", m_tex), ("plain", m_plain)):
+        a, s, sm, nn = sc.sample_material(mid, t0["mat_uv"])
+        assert np.array_equal(a, t0[f"mat_{name}_albedo"]) and np.array_equal(s, t0[f"mat_{name}_specular"])
+        assert np.array_equal(sm, t0[f"mat_{name}_smoothness"])
+        np.testing.assert_allclose(nn, t0[f"mat_{name}_normal"], rtol=0, atol=1e-7)
+    # texel indexing at the edges: u = 1 and v = 0 stay inside the texture (last column / last row)
+    uv = t0["mat_uv"]
+    alb = t0["map_albedo"].astype(np.float32) / np.float32(255)
+    edge = np.where((uv[:, 0] == 1.0) & (uv[:, 1] == 0.0))[0]
+    assert len(edge) == 1 and np.array_equal(t0["mat_tex_albedo"][edge[0]], alb[-1, -1])
+    for size, sigma, key in ((2, 0.7, "gauss_2_0p7"), (32, 10.0, "gauss_32_10"), (1, 3.0, "gauss_1_3")):
+        np.testing.assert_allclose(oracle.make_gaussian(size, sigma), t0[key], rtol=1e-6, atol=0)
+    assert np.array_equal(oracle.make_mean(3), t0["mean_3"])
+    ramp = t0["tone_in"]
+    np.testing.assert_allclose(oracle.apply_aces(ramp), t0["tone_aces"], rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(oracle.gamma_correct(np.clip(ramp, 0, 1), 2.2), t0["tone_gamma"], rtol=1e-6, atol=1e-7)
+    assert np.array_equal(oracle.apply_threshold(ramp, 3.0), t0["tone_threshold"])
+    assert np.array_equal(oracle.image_add(ramp, ramp[:, ::-1].copy(), 0.5), t0["tone_add"])
+    np.testing.assert_allclose(oracle.normalize_image(ramp, 2048), t0["tone_normalize"], rtol=1e-7)
+    assert np.array_equal(oracle.to_ppm_bytes(np.clip(ramp / 12, 0, 1.2)), t0["tone_ppm"])
