@@ -641,6 +641,10 @@ int plan_render(pt_scene *scene, const pt_camera *camera, uint32_t seed, int sam
     p.mtiles_x = (p.tiles_x + 7) / 8;
     p.mtiles_y = (p.tiles_y + 7) / 8;
     const int n_slices = p.plan.n_split * p.plan.slices_per_split;
+    if (n_slices > kMaxSlices) PT_FAIL("pt_render_accumulate: slice plan exceeds the slice table");
+    p.div_slices = make_udiv((uint32_t)n_slices);
+    p.div_mtiles_x = make_udiv((uint32_t)p.mtiles_x);
+    for (int k = 0; k < n_slices; k++) slice_range(p.plan, k, p.slice_s0[k], p.slice_s1[k]);
     const uint64_t n_items = (uint64_t)p.mtiles_x * p.mtiles_y * 64 * n_slices;
     if (n_items >= 0xFFFF0000ull) PT_FAIL("pt_render_accumulate: too many work items");
     p.n_items = (uint32_t)n_items;

@@ -241,8 +241,9 @@ __device__ __forceinline__ void entity_block(const PtSceneDev &sc, Lane &L, Stat
     if (d.x < 0.0f) { float delta = o.x - midx; o.x = midx - delta; d.x = -d.x; a |= 4; }
     if (d.y < 0.0f) { float delta = o.y - midy; o.y = midy - delta; d.y = -d.y; a |= 2; }
     if (d.z < 0.0f) { float delta = o.z - midz; o.z = midz - delta; d.z = -d.z; a |= 1; }
-    /* fracs of the mirrored ray; for un-mirrored components this is the value the original ray holds */
-    const float frx = clamp_frac(d.x), fry = clamp_frac(d.y), frz = clamp_frac(d.z);
+    /* fracs of the mirrored ray (dgf:67-68 recomputes them): 1 / -x == -(1 / x) exactly and the clamp bounds are
+     * symmetric, so a mirrored component's frac is the negated frac of the original one -- no second division */
+    const float frx = (a & 4) ? -fr.x : fr.x, fry = (a & 2) ? -fr.y : fr.y, frz = (a & 1) ? -fr.z : fr.z;
     const float t0x = (e.region_min[0] - o.x) * frx, t1x = (e.region_max[0] - o.x) * frx;
     const float t0y = (e.region_min[1] - o.y) * fry, t1y = (e.region_max[1] - o.y) * fry;
     const float t0z = (e.region_min[2] - o.z) * frz, t1z = (e.region_max[2] - o.z) * frz;

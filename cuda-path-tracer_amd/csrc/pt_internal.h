@@ -35,6 +35,26 @@ struct SlicePlan {
     int slices_per_split;
 };
 SlicePlan make_slice_plan(int sample_begin, int sample_end, int n_split);
+/* samples [s0, s1) of slice `slice`: split buffer z = slice / slices_per_split takes the z-th of n_split equal parts
+ * of the range, cut again into slices_per_split equal parts */
+void slice_range(const SlicePlan &pl, int slice, int &s0, int &s1);
+
+/* unsigned division by a launch-invariant divisor without a divide instruction (Granlund-Montgomery): exact for
+ * every 32-bit numerator; the kernel evaluates it on wave-uniform values, i.e. on the scalar unit */
+struct UDiv {
+    uint32_t mul, sh1, sh2;
+};
+inline UDiv make_udiv(uint32_t d) {
+    UDiv r;
+    uint32_t l = 0;
+    while ((1ull << l) < d) l++;                                    /* ceil(log2 d) */
+    r.mul = (uint32_t)((((1ull << l) - d) << 32) / d + 1);
+    r.sh1 = l < 1 ? l : 1;
+    r.sh2 = l > 1 ? l - 1 : 0;
+    return r;
+}
+
+static constexpr int kMaxSlices = 64;
 
 struct RenderParams {
     PtSceneDev sc;
@@ -45,9 +65,14 @@ struct RenderParams {
     int mtiles_x, mtiles_y;      /* 8x8-tile macro tiles covering the tiles */
     uint32_t n_items;            /* mtiles_x * mtiles_y * 64 tiles * slices */
     uint32_t n_queues;           /* == gridDim.x: every workgroup owns one contiguous range of the items */
+    uint32_t items_per_queue;    /* ceil(n_items / n_queues): queue q owns items [q * per, (q + 1) * per) cut at n_items */
     uint32_t *tickets;           /* n_queues cursors, then the number of exhausted queues; zeroed before the launch */
     float *partials;             /* [n_split * slices_per_split][H*W][3] */
     unsigned long long *stats;   /* 7 counters, or null */
+    UDiv div_slices;             /* item / n_slices */
+    UDiv div_mtiles_x;           /* macro tile / mtiles_x */
+    int slice_s0[kMaxSlices];    /* sample range [s0, s1) of every slice of the plan (slice_range on the host) */
+    int slice_s1[kMaxSlices];
     int done_quota;              /* finished lanes per wave at which it leaves the geometry blocks to shade / refill */
     int leaf_quota;              /* triangle runs waiting per wave at which it tests them before walking on */
 };

@@ -34,10 +34,14 @@ __device__ __forceinline__ CoopLds *coop_area(float4 *lds, int max_depth) {
 }
 
 /* ------------------------------------------------------------------ shading (fast math allowed) */
+/* The library is built with -ffp-contract=off because geometry must round like a scalar IEEE evaluation.  Shading is
+ * compared with the reference by tolerance, so its functions let the compiler fuse multiply-adds (PT_SHADING_FP). */
+#define PT_SHADING_FP _Pragma("clang fp contract(fast)")
 
 __device__ __forceinline__ float fast_rsq(float x) { return __builtin_amdgcn_rsqf(x); }
 __device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 __device__ __forceinline__ V3 fast_normalized(V3 v) {
+    PT_SHADING_FP
     float r = fast_rsq(v.x * v.x + v.y * v.y + v.z * v.z);
     return mk(v.x * r, v.y * r, v.z * r);
 }
@@ -49,7 +53,9 @@ __device__ __forceinline__ float fast_pow(float x, float y) {
 __device__ __forceinline__ float sin_rev(float rev) { return __builtin_amdgcn_sinf(rev); }
 __device__ __forceinline__ float cos_rev(float rev) { return __builtin_amdgcn_cosf(rev); }
 
-__device__ __forceinline__ float luminosity(V3 c) { return c.x * 0.2126f + c.y * 0.7152f + c.z * 0.0722f; }  /* src/util.cuh:40 */
+__device__ __forceinline__ float luminosity(V3 c) {
+    PT_SHADING_FP
+    return c.x * 0.2126f + c.y * 0.7152f + c.z * 0.0722f; }  /* src/util.cuh:40 */
 
 __device__ __forceinline__ int to_index(float f, int n) {   /* C truncation, clamped into the image */
     if (!(f >= 0.0f)) return 0;
@@ -75,6 +81,7 @@ __device__ __forceinline__ float tex_gray(const uint8_t *data, int w, int h, flo
 /* src/scene.cuh:36-82 */
 template <bool STATS>
 __device__ __forceinline__ V3 sample_hdri(const PtSceneDev &sc, V3 v, Stats &st) {
+    PT_SHADING_FP
     if (!sc.has_hdri) return mk(0.f, 0.f, 0.f);
     if (STATS) st.env_lookups++;
     const int W = sc.hdri_w, H = sc.hdri_h;
@@ -117,6 +124,7 @@ __device__ __forceinline__ V3 sample_hdri(const PtSceneDev &sc, V3 v, Stats &st)
 struct Basis { V3 t, b, n; };
 /* src/renderer.cu:168-175 */
 __device__ __forceinline__ Basis tangent_space(V3 n) {
+    PT_SHADING_FP
     V3 helper = mk(1.f, 0.f, 0.f);
     if (fabsf(n.x) > 0.99f) helper = mk(0.f, 0.f, 1.f);
     Basis B;
@@ -127,11 +135,13 @@ __device__ __forceinline__ Basis tangent_space(V3 n) {
 }
 /* vec3 * mat3(t,b,n) of src/vector.cuh:186-192 */
 __device__ __forceinline__ V3 to_world(V3 v, const Basis &B) {
+    PT_SHADING_FP
     return mk(v.x * B.t.x + v.y * B.b.x + v.z * B.n.x, v.x * B.t.y + v.y * B.b.y + v.z * B.n.y,
               v.x * B.t.z + v.y * B.b.z + v.z * B.n.z);
 }
 /* src/renderer.cu:157-163 */
 __device__ __forceinline__ V3 sample_hemisphere(V3 dir, float alpha, float xi_c, float xi_p) {
+    PT_SHADING_FP
     const float cos_theta = fast_pow(xi_c, fast_rcp(alpha + 1.0f));
     const float sin_theta = __builtin_sqrtf(fmaxf(1.0f - cos_theta * cos_theta, 0.0f));
     const V3 ts = mk(cos_rev(xi_p) * sin_theta, sin_rev(xi_p) * sin_theta, cos_theta);
@@ -167,6 +177,7 @@ __device__ __forceinline__ void camera_ray(const pt_camera &cam, int u, int v, c
 template <bool STATS>
 __device__ __forceinline__ void shade_hit(const PtSceneDev &sc, const Best &best, const Surface &sf, const float xi[4],
                                           V3 &o, V3 &d, V3 &atten, V3 &result, Stats &st) {
+    PT_SHADING_FP
     const PtMaterial &m = sc.materials[sc.entities[best.entity].material];
     V3 ts_normal = mk(0.f, 0.f, 1.f);
     if (m.map[2]) {
@@ -347,7 +358,7 @@ __global__ void __launch_bounds__(kBlock) sample_material_kernel(PtSceneDev sc, 
 }
 
 /* ------------------------------------------------------------------ persistent render kernel */
-__device__ __forceinline__ void slice_range(const SlicePlan &pl, int slice, int &s0, int &s1) {
+void slice_range(const SlicePlan &pl, int slice, int &s0, int &s1) {
     const int z = slice / pl.slices_per_split, j = slice - z * pl.slices_per_split;
     const long long N = pl.n_samples;
     const int zb = pl.sample_begin + (int)((N * z) / pl.n_split);
@@ -355,6 +366,11 @@ __device__ __forceinline__ void slice_range(const SlicePlan &pl, int slice, int 
     const long long M = ze - zb;
     s0 = zb + (int)((M * j) / pl.slices_per_split);
     s1 = zb + (int)((M * (j + 1)) / pl.slices_per_split);
+}
+
+__device__ __forceinline__ uint32_t udiv(uint32_t n, const UDiv &d) {
+    const uint32_t t = __umulhi(d.mul, n);
+    return (t + ((n - t) >> d.sh1)) >> d.sh2;
 }
 
 template <bool STATS, int WAVES, bool COOP>
@@ -368,15 +384,16 @@ __global__ void __launch_bounds__(kBlock, WAVES) render_kernel(RenderParams P) {
     const int n_slices = P.plan.n_split * P.plan.slices_per_split;
     const size_t n_pixels = (size_t)W * (size_t)H;
 
-    /* wave-uniform pool: the item this wave is handing out pixels of */
-    uint32_t pool_item = 0;
+    /* wave-uniform pool: the item this wave is handing out pixels of, decoded once when it is pulled (on the scalar
+     * unit: every value below is the same in all lanes): first pixel of its 8x8 tile, slice, the slice's samples */
+    int pool_px0 = 0, pool_py0 = 0, pool_slice = 0, pool_s0 = 0, pool_s1 = 0;
     int pool_next = 64;
     bool exhausted = false;
     /* Work queues.  The item space (macro-tile order, all slices of a tile adjacent) is cut into one
      * contiguous range per workgroup, so the waves of a workgroup -- which share a CU and its L1 --
      * trace neighbouring pixels; workgroups b, b+8, ... tend to share an XCD and its L2 (a speed
      * matter only), so they get adjacent ranges.  A wave whose range is empty steals from the next. */
-    const uint32_t nq = P.n_queues;
+    const uint32_t nq = P.n_queues, per_queue = P.items_per_queue;
     uint32_t q;
     {
         const uint32_t b = blockIdx.x, per = nq / 8u, rem = nq % 8u, x = b % 8u;
@@ -438,16 +455,17 @@ __global__ void __launch_bounds__(kBlock, WAVES) render_kernel(RenderParams P) {
             const int rank = __popcll(need & ((1ull << lane) - 1ull));
             int assigned = 0;
             bool got = false;
-            uint32_t my_item = 0;
-            int my_slot = 0;
+            int my_slot = 0, my_px0 = 0, my_py0 = 0, my_slice = 0, my_s0 = 0, my_s1 = 0;
             while (assigned < n_need) {
                 if (pool_next >= 64) {
                     if (exhausted) break;
                     uint32_t id = 0xFFFFFFFFu;
                     if (lane == 0) {
                         for (;;) {
-                            const uint32_t lo = (uint32_t)(((unsigned long long)P.n_items * q) / nq);
-                            const uint32_t hi = (uint32_t)(((unsigned long long)P.n_items * (q + 1u)) / nq);
+                            /* queue q holds items [q * per, min((q + 1) * per, n_items)) */
+                            const unsigned long long first = (unsigned long long)per_queue * q;
+                            const uint32_t lo = (uint32_t)(first < P.n_items ? first : P.n_items);
+                            const uint32_t hi = (uint32_t)(first + per_queue < P.n_items ? first + per_queue : P.n_items);
                             const uint32_t t = atomicAdd(&P.tickets[q], 1u);
                             if (t < hi - lo) { id = lo + t; break; }
                             /* this range is finished for good; the first draw past its end reports it, and once
@@ -463,14 +481,22 @@ __global__ void __launch_bounds__(kBlock, WAVES) render_kernel(RenderParams P) {
                     q = (uint32_t)__builtin_amdgcn_readfirstlane((int)q);
                     probes = (uint32_t)__builtin_amdgcn_readfirstlane((int)probes);
                     if (id == 0xFFFFFFFFu) { exhausted = true; break; }
-                    pool_item = id;
+                    /* item -> (tile in macro-tile order, slice) */
+                    const uint32_t tseq = udiv(id, P.div_slices);
+                    pool_slice = (int)(id - tseq * (uint32_t)n_slices);
+                    const uint32_t mt = tseq >> 6, lt = tseq & 63u;
+                    const uint32_t mty = udiv(mt, P.div_mtiles_x), mtx = mt - mty * (uint32_t)P.mtiles_x;
+                    pool_px0 = (int)((mtx * 8u + (lt & 7u)) * 8u);
+                    pool_py0 = (int)((mty * 8u + (lt >> 3)) * 8u);
+                    pool_s0 = P.slice_s0[pool_slice];
+                    pool_s1 = P.slice_s1[pool_slice];
                     pool_next = 0;
                 }
                 const int k = min(n_need - assigned, 64 - pool_next);
                 if (wants && rank >= assigned && rank < assigned + k) {
                     got = true;
-                    my_item = pool_item;
                     my_slot = pool_next + (rank - assigned);
+                    my_px0 = pool_px0; my_py0 = pool_py0; my_slice = pool_slice; my_s0 = pool_s0; my_s1 = pool_s1;
                 }
                 pool_next += k;
                 assigned += k;
@@ -479,17 +505,13 @@ __global__ void __launch_bounds__(kBlock, WAVES) render_kernel(RenderParams P) {
                 if (!got) {
                     done = true;
                 } else {
-                    /* item -> (tile in macro-tile order, slice) */
-                    const uint32_t tseq = my_item / (uint32_t)n_slices;
-                    slice = (int)(my_item - tseq * (uint32_t)n_slices);
-                    const uint32_t mt = tseq >> 6, lt = tseq & 63u;
-                    const int tx = (int)((mt % (uint32_t)P.mtiles_x) * 8u + (lt & 7u));
-                    const int ty = (int)((mt / (uint32_t)P.mtiles_x) * 8u + (lt >> 3));
-                    const int px = tx * 8 + (my_slot & 7), py = ty * 8 + (my_slot >> 3);
+                    const int px = my_px0 + (my_slot & 7), py = my_py0 + (my_slot >> 3);
                     if (px < W && py < H) {
                         pixel = py * W + px;
                         pxy = (py << 16) | px;
-                        slice_range(P.plan, slice, s_cur, s_end);
+                        slice = my_slice;
+                        s_cur = my_s0;
+                        s_end = my_s1;
                         accum = mk(0.f, 0.f, 0.f);
                     }
                 }
@@ -634,6 +656,7 @@ int launch_render(RenderParams p, int n_cu, int max_queues, bool heavy, hipStrea
     if (blocks < 1) blocks = 1;
     if (blocks > max_queues) blocks = max_queues;
     p.n_queues = (uint32_t)blocks;
+    p.items_per_queue = (uint32_t)(((uint64_t)p.n_items + (uint64_t)blocks - 1) / (uint64_t)blocks);
     const dim3 grid((unsigned)blocks), block(kBlock);
     if (heavy) {
         /* deep octrees need so much LDS for their stacks that fewer workgroups fit than the registers of the

@@ -20,7 +20,23 @@
 #define K_BFE(i)    asm volatile("v_bfe_u32 %0, %0, 3, 5" : "+v"(x[i]));
 #define K_CMP(i)    asm volatile("v_cmp_lt_f32 vcc, %0, %1" : : "v"(x[i]), "v"(a) : "vcc");
 #define K_CMPS(i)   asm volatile("v_cmp_lt_f32 s[20:21], %0, %1" : : "v"(x[i]), "v"(a) : "s20", "s21");
-#define K_CND(i)    asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(x[i]) : "v"(a) : "vcc");
+#define K_CND(i)    asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(x[i]) : "v"(a));
+#define K_CND64(i)  asm volatile("v_cndmask_b32_e64 %0, %0, %1, s[22:23]" : "+v"(x[i]) : "v"(a));
+#define K_CNDK(i)   asm volatile("v_cndmask_b32_e64 %0, 0, 4, s[22:23]" : "=v"(x[i]));
+#define K_MAXU(i)   asm volatile("v_max_u32 %0, %0, %1" : "+v"(x[i]) : "v"(a));
+#define K_OR3(i)    asm volatile("v_or3_b32 %0, %0, %1, %2" : "+v"(x[i]) : "v"(a), "v"(b));
+#define K_LSHLOR(i) asm volatile("v_lshl_or_b32 %0, %0, 3, %1" : "+v"(x[i]) : "v"(a));
+#define K_OR(i)     asm volatile("v_or_b32 %0, %0, %1" : "+v"(x[i]) : "v"(a));
+#define K_LSHLV(i)  asm volatile("v_lshlrev_b32 %0, %1, %0" : "+v"(x[i]) : "v"(a));
+#define K_CMPU(i)   asm volatile("v_cmp_gt_u32 vcc, %0, %1" : : "v"(x[i]), "v"(a) : "vcc");
+#define K_FMAC(i)   asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(x[i]) : "v"(a), "v"(b));
+#define K_MULK(i)   asm volatile("v_mul_f32 %0, 0.5, %0" : "+v"(x[i]));
+#define K_ADDS(i)   asm volatile("v_add_f32 %0, s24, %0" : "+v"(x[i]));
+#define K_SUB(i)    asm volatile("v_sub_f32 %0, %0, %1" : "+v"(x[i]) : "v"(a));
+#define K_MAXF(i)   asm volatile("v_max_f32 %0, %0, %1" : "+v"(x[i]) : "v"(a));
+#define K_ASHR(i)   asm volatile("v_ashrrev_i32 %0, 31, %0" : "+v"(x[i]));
+#define K_BPERM(i)  asm volatile("ds_bpermute_b32 %0, %1, %0\n s_waitcnt lgkmcnt(0)" : "+v"(x[i]) : "v"(a));
+#define K_DPP(i)    asm volatile("v_mov_b32_dpp %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" : "+v"(x[i]));
 #define K_CMPCND(i) asm volatile("v_cmp_lt_f32 vcc, %0, %1\n v_cndmask_b32 %0, %0, %2, vcc" : "+v"(x[i]) : "v"(a), "v"(b) : "vcc");
 #define K_PKMUL(i)  asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(y[i]) : "v"(c));
 #define K_PKADD(i)  asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(y[i]) : "v"(c));
@@ -51,6 +67,7 @@ typedef float f2 __attribute__((ext_vector_type(2)));
         float a = a_, b = b_;                                                                           \
         f2 c = {a_, b_};                                                                                \
         asm volatile("" : "+v"(a), "+v"(b), "+v"(c));                                                   \
+        asm volatile("v_cmp_lt_f32 vcc, %0, %1\n s_mov_b64 s[22:23], vcc\n s_mov_b32 s24, 0x3f000000" : : "v"(a), "v"(b) : "vcc", "s22", "s23", "s24");                                                  \
         for (int it = 0; it < iters; it++) {                                                            \
             REP8(BODY) REP8(BODY) REP8(BODY) REP8(BODY) REP8(BODY) REP8(BODY) REP8(BODY) REP8(BODY)     \
         }                                                                                               \
@@ -60,7 +77,8 @@ typedef float f2 __attribute__((ext_vector_type(2)));
     }
 
 #define LIST(F) F(FMA, 1) F(ADD, 1) F(MUL, 1) F(SUBREV, 1) F(MIN, 1) F(MAX3, 1) F(MED3, 1) F(MOV, 1) F(AND, 1) F(XOR, 1) F(LSHL, 1) F(ADDU, 1) \
-    F(ADD3, 1) F(LSHLADD, 1) F(BFE, 1) F(BFI, 1) F(BCNT, 1) F(FFBL, 1) F(CVT, 1) F(MBCNT, 1) F(CMP, 1) F(CMPS, 1) F(CND, 1) F(CMPCND, 2)      \
+    F(ADD3, 1) F(LSHLADD, 1) F(BFE, 1) F(BFI, 1) F(BCNT, 1) F(FFBL, 1) F(CVT, 1) F(MBCNT, 1) F(CMP, 1) F(CMPS, 1) F(CMPU, 1) F(CND, 1) F(CND64, 1) F(CNDK, 1) F(CMPCND, 2) F(MAXU, 1) F(MAXF, 1) F(OR, 1) F(OR3, 1) F(LSHLOR, 1) F(LSHLV, 1) \
+    F(FMAC, 1) F(MULK, 1) F(ADDS, 1) F(SUB, 1) F(ASHR, 1) F(BPERM, 1) F(DPP, 1)      \
     F(PKMUL, 1) F(PKADD, 1) F(PKFMA, 1) F(RCP, 1) F(MULLO, 1) F(MAD24, 1) F(READFL, 1) F(SALU, 1)
 
 #define DEF(NAME, N) KERNEL(NAME, K_##NAME)
