@@ -634,6 +634,7 @@ int plan_render(pt_scene *scene, const pt_camera *camera, uint32_t seed, int sam
     memset(&p, 0, sizeof p);
     p.sc = scene->dev;
     p.cam = *camera;
+    p.camk = make_cam_consts(*camera);
     p.seed = seed;
     p.plan = make_slice_plan(sample_begin, sample_end, n_split);
     p.tiles_x = (camera->res_x + 7) / 8;

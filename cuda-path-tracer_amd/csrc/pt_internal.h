@@ -54,11 +54,34 @@ inline UDiv make_udiv(uint32_t d) {
     return r;
 }
 
+/* what create_camera_ray (src/renderer.cu:60-87) derives from the camera alone, evaluated once on the host with the
+ * same fp32 operations the per-ray code would use (this library's host code is built without contraction too) */
+struct CamConsts {
+    float right[3];          /* -cross(direction, up) */
+    float fd[3];             /* focal_length * direction */
+    float aspect;            /* (float)res_x / (float)res_y */
+    float res_x_f, res_y_f;
+    float half_aperture;     /* aperture / 2 */
+};
+inline CamConsts make_cam_consts(const pt_camera &c) {
+    CamConsts k;
+    const float *d = c.direction, *u = c.up;
+    const float cx = (d[1] * u[2]) - (d[2] * u[1]), cy = (d[2] * u[0]) - (d[0] * u[2]), cz = (d[0] * u[1]) - (d[1] * u[0]);
+    k.right[0] = -cx; k.right[1] = -cy; k.right[2] = -cz;
+    for (int i = 0; i < 3; i++) k.fd[i] = c.focal_length * d[i];
+    k.res_x_f = (float)c.res_x;
+    k.res_y_f = (float)c.res_y;
+    k.aspect = k.res_x_f / k.res_y_f;
+    k.half_aperture = c.aperture / 2;
+    return k;
+}
+
 static constexpr int kMaxSlices = 64;
 
 struct RenderParams {
     PtSceneDev sc;
     pt_camera cam;
+    CamConsts camk;
     uint32_t seed;
     SlicePlan plan;
     int tiles_x, tiles_y;        /* 8x8-pixel tiles covering the image */

@@ -148,21 +148,19 @@ __device__ __forceinline__ V3 sample_hemisphere(V3 dir, float alpha, float xi_c,
     return to_world(ts, tangent_space(dir));
 }
 
-/* src/renderer.cu:60-87; xi = Philox block 0 of (pixel, sample) */
-__device__ __forceinline__ void camera_ray(const pt_camera &cam, int u, int v, const float xi[4], V3 &ro, V3 &rd) {
+/* src/renderer.cu:60-87; xi = Philox block 0 of (pixel, sample); k = make_cam_consts(cam) */
+__device__ __forceinline__ void camera_ray(const pt_camera &cam, const CamConsts &k, int u, int v, const float xi[4], V3 &ro, V3 &rd) {
     const V3 pos = mk(cam.position[0], cam.position[1], cam.position[2]);
     const V3 dir = mk(cam.direction[0], cam.direction[1], cam.direction[2]);
     const V3 up = mk(cam.up[0], cam.up[1], cam.up[2]);
-    const float n_u = (((float)u + xi[0]) / (float)cam.res_x) - 0.5f;
-    const float n_v = (((float)v + xi[1]) / (float)cam.res_y) - 0.5f;
-    const float aspect = (float)cam.res_x / (float)cam.res_y;
-    const V3 c = cross3(dir, up);
-    const V3 right = mk(-c.x, -c.y, -c.z);
-    const V3 point = (((aspect * (n_u * right)) - (n_v * up)) + pos) + (cam.focal_length * dir);
+    const V3 right = mk(k.right[0], k.right[1], k.right[2]);
+    const float n_u = (((float)u + xi[0]) / k.res_x_f) - 0.5f;
+    const float n_v = (((float)v + xi[1]) / k.res_y_f) - 0.5f;
+    const V3 point = (((k.aspect * (n_u * right)) - (n_v * up)) + pos) + mk(k.fd[0], k.fd[1], k.fd[2]);
     V3 ray_dir = normalized(point - pos);
     V3 ray_orig = pos;
     if (cam.aperture > 0.01f) {
-        const float r = __builtin_sqrtf(xi[2]) * (cam.aperture / 2);
+        const float r = __builtin_sqrtf(xi[2]) * k.half_aperture;
         const float dx = cos_rev(xi[3]) * r, dy = sin_rev(xi[3]) * r;
         const V3 off = (dx * right) - (dy * up);
         const V3 focal_point = ray_orig + (cam.focus_distance * (1.0f / dot3(dir, ray_dir))) * ray_dir;
@@ -308,14 +306,14 @@ __global__ void __launch_bounds__(kBlock) trace_kernel(PtSceneDev sc, const floa
     }
 }
 
-__global__ void __launch_bounds__(kBlock) camera_rays_kernel(pt_camera cam, uint32_t seed, int sample, float *__restrict__ rays) {
+__global__ void __launch_bounds__(kBlock) camera_rays_kernel(pt_camera cam, CamConsts camk, uint32_t seed, int sample, float *__restrict__ rays) {
     const int n = cam.res_x * cam.res_y;
     const int i = blockIdx.x * kBlock + threadIdx.x;
     if (i >= n) return;
     float xi[4];
     rng_block((uint32_t)i, (uint32_t)sample, 0u, seed, xi);
     V3 o, d;
-    camera_ray(cam, i % cam.res_x, i / cam.res_x, xi, o, d);
+    camera_ray(cam, camk, i % cam.res_x, i / cam.res_x, xi, o, d);
     float *r = rays + 6 * (size_t)i;
     r[0] = o.x; r[1] = o.y; r[2] = o.z; r[3] = d.x; r[4] = d.y; r[5] = d.z;
 }
@@ -521,7 +519,7 @@ __global__ void __launch_bounds__(kBlock, WAVES) render_kernel(RenderParams P) {
             float xi[4];
             rng_block((uint32_t)pixel, (uint32_t)s_cur, 0u, P.seed, xi);
             V3 o, d;
-            camera_ray(P.cam, pxy & 0xFFFF, pxy >> 16, xi, o, d);
+            camera_ray(P.cam, P.camk, pxy & 0xFFFF, pxy >> 16, xi, o, d);
             atten = mk(1.f, 1.f, 1.f);
             result = mk(0.f, 0.f, 0.f);
             bounce = 0;
@@ -631,7 +629,7 @@ int launch_sample_material(const PtSceneDev &sc, int material, const float *d_uv
 int launch_camera_rays(const pt_camera &cam, uint32_t seed, int sample, float *d_rays, hipStream_t stream) {
     const int n = cam.res_x * cam.res_y;
     if (n <= 0) return 0;
-    hipLaunchKernelGGL(camera_rays_kernel, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, cam, seed, sample, d_rays);
+    hipLaunchKernelGGL(camera_rays_kernel, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, cam, make_cam_consts(cam), seed, sample, d_rays);
     PT_HIP(hipGetLastError());
     return 0;
 }
