@@ -36,6 +36,26 @@
 #define K_MAXF(i)   asm volatile("v_max_f32 %0, %0, %1" : "+v"(x[i]) : "v"(a));
 #define K_ASHR(i)   asm volatile("v_ashrrev_i32 %0, 31, %0" : "+v"(x[i]));
 #define K_BPERM(i)  asm volatile("ds_bpermute_b32 %0, %1, %0\n s_waitcnt lgkmcnt(0)" : "+v"(x[i]) : "v"(a));
+#define K_MAD64(i)  asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(z[i]) : "v"(a), "v"(b) : "vcc");
+#define K_MULHI(i)  asm volatile("v_mul_hi_u32 %0, %0, %1" : "+v"(x[i]) : "v"(a));
+#define K_DIVSC(i)  asm volatile("v_div_scale_f32 %0, vcc, %0, %1, %0" : "+v"(x[i]) : "v"(a) : "vcc");
+#define K_DIVFM(i)  asm volatile("v_div_fmas_f32 %0, %0, %1, %2" : "+v"(x[i]) : "v"(a), "v"(b));
+#define K_DIVFX(i)  asm volatile("v_div_fixup_f32 %0, %0, %1, %2" : "+v"(x[i]) : "v"(a), "v"(b));
+#define K_SQRT(i)   asm volatile("v_sqrt_f32 %0, %0" : "+v"(x[i]));
+#define K_RSQ(i)    asm volatile("v_rsq_f32 %0, %0" : "+v"(x[i]));
+#define K_EXP(i)    asm volatile("v_exp_f32 %0, %0" : "+v"(x[i]));
+#define K_LOG(i)    asm volatile("v_log_f32 %0, %0" : "+v"(x[i]));
+#define K_SIN(i)    asm volatile("v_sin_f32 %0, %0" : "+v"(x[i]));
+#define K_FRACT(i)  asm volatile("v_fract_f32 %0, %0" : "+v"(x[i]));
+#define K_LDEXP(i)  asm volatile("v_ldexp_f32 %0, %0, %1" : "+v"(x[i]) : "v"(a));
+#define K_RDLANE(i) asm volatile("v_readlane_b32 s20, %0, 5" : : "v"(x[i]) : "s20");
+#define K_WRLANE(i) asm volatile("v_writelane_b32 %0, s24, 5" : "+v"(x[i]));
+#define K_CVTUB(i)  asm volatile("v_cvt_f32_ubyte0 %0, %0" : "+v"(x[i]));
+#define K_CVTI(i)   asm volatile("v_cvt_u32_f32 %0, %0" : "+v"(x[i]));
+#define K_LSHL64(i) asm volatile("v_lshlrev_b64 %0, 3, %0" : "+v"(z[i]));
+#define K_LSHLADD64(i) asm volatile("v_lshl_add_u64 %0, %0, 3, %1" : "+v"(z[i]) : "v"(z[(i+1)&7]));
+#define K_MOV64(i)  asm volatile("v_mov_b64 %0, %1" : "=v"(z[i]) : "v"(z[(i+1)&7]));
+#define K_BITOP3(i) asm volatile("v_bitop3_b32 %0, %0, %1, %2 bitop3:0x36" : "+v"(x[i]) : "v"(a), "v"(b));
 #define K_DPP(i)    asm volatile("v_mov_b32_dpp %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" : "+v"(x[i]));
 #define K_CMPCND(i) asm volatile("v_cmp_lt_f32 vcc, %0, %1\n v_cndmask_b32 %0, %0, %2, vcc" : "+v"(x[i]) : "v"(a), "v"(b) : "vcc");
 #define K_PKMUL(i)  asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(y[i]) : "v"(c));
@@ -63,7 +83,8 @@ typedef float f2 __attribute__((ext_vector_type(2)));
     __global__ void __launch_bounds__(256) k_##NAME(float *out, int iters, float a_, float b_) {         \
         float x[8];                                                                                     \
         f2 y[8];                                                                                        \
-        for (int i = 0; i < 8; i++) { x[i] = threadIdx.x + i; y[i] = f2{x[i], x[i] + 1.f}; }            \
+        unsigned long long z[8];                                                                        \
+        for (int i = 0; i < 8; i++) { x[i] = threadIdx.x + i; y[i] = f2{x[i], x[i] + 1.f}; z[i] = threadIdx.x * 77ull + i; }            \
         float a = a_, b = b_;                                                                           \
         f2 c = {a_, b_};                                                                                \
         asm volatile("" : "+v"(a), "+v"(b), "+v"(c));                                                   \
@@ -72,13 +93,15 @@ typedef float f2 __attribute__((ext_vector_type(2)));
             REP8(BODY) REP8(BODY) REP8(BODY) REP8(BODY) REP8(BODY) REP8(BODY) REP8(BODY) REP8(BODY)     \
         }                                                                                               \
         float s = 0;                                                                                    \
-        for (int i = 0; i < 8; i++) s += x[i] + y[i].x + y[i].y;                                        \
+        for (int i = 0; i < 8; i++) s += x[i] + y[i].x + y[i].y + (float)z[i];                                        \
         out[blockIdx.x * 256 + threadIdx.x] = s;                                                        \
     }
 
 #define LIST(F) F(FMA, 1) F(ADD, 1) F(MUL, 1) F(SUBREV, 1) F(MIN, 1) F(MAX3, 1) F(MED3, 1) F(MOV, 1) F(AND, 1) F(XOR, 1) F(LSHL, 1) F(ADDU, 1) \
     F(ADD3, 1) F(LSHLADD, 1) F(BFE, 1) F(BFI, 1) F(BCNT, 1) F(FFBL, 1) F(CVT, 1) F(MBCNT, 1) F(CMP, 1) F(CMPS, 1) F(CMPU, 1) F(CND, 1) F(CND64, 1) F(CNDK, 1) F(CMPCND, 2) F(MAXU, 1) F(MAXF, 1) F(OR, 1) F(OR3, 1) F(LSHLOR, 1) F(LSHLV, 1) \
-    F(FMAC, 1) F(MULK, 1) F(ADDS, 1) F(SUB, 1) F(ASHR, 1) F(BPERM, 1) F(DPP, 1)      \
+    F(FMAC, 1) F(MULK, 1) F(ADDS, 1) F(SUB, 1) F(ASHR, 1) F(BPERM, 1) F(DPP, 1) \
+    F(MAD64, 1) F(MULHI, 1) F(DIVSC, 1) F(DIVFM, 1) F(DIVFX, 1) F(SQRT, 1) F(RSQ, 1) F(EXP, 1) F(LOG, 1) F(SIN, 1) F(FRACT, 1) F(LDEXP, 1) F(RDLANE, 1) \
+    F(WRLANE, 1) F(CVTUB, 1) F(CVTI, 1) F(LSHL64, 1) F(LSHLADD64, 1) F(MOV64, 1) F(BITOP3, 1)      \
     F(PKMUL, 1) F(PKADD, 1) F(PKFMA, 1) F(RCP, 1) F(MULLO, 1) F(MAD24, 1) F(READFL, 1) F(SALU, 1)
 
 #define DEF(NAME, N) KERNEL(NAME, K_##NAME)
