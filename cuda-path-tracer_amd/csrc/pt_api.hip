@@ -645,7 +645,11 @@ int plan_render(pt_scene *scene, const pt_camera *camera, uint32_t seed, int sam
     if (n_slices > kMaxSlices) PT_FAIL("pt_render_accumulate: slice plan exceeds the slice table");
     p.div_slices = make_udiv((uint32_t)n_slices);
     p.div_mtiles_x = make_udiv((uint32_t)p.mtiles_x);
-    for (int k = 0; k < n_slices; k++) slice_range(p.plan, k, p.slice_s0[k], p.slice_s1[k]);
+    for (int k = 0; k < n_slices; k++) {
+        slice_range(p.plan, k, p.slice_s0[k], p.slice_s1[k]);
+        /* a lane counts the samples of its slice down in 16 bits */
+        if (p.slice_s1[k] - p.slice_s0[k] > 0xFFFF) PT_FAIL("pt_render_accumulate: more than 65535 samples per slice (split the sample range over several calls)");
+    }
     const uint64_t n_items = (uint64_t)p.mtiles_x * p.mtiles_y * 64 * n_slices;
     if (n_items >= 0xFFFF0000ull) PT_FAIL("pt_render_accumulate: too many work items");
     p.n_items = (uint32_t)n_items;
@@ -663,6 +667,7 @@ int check_render_args(const char *who, pt_scene *scene, const pt_camera *camera,
     if (!scene || !camera || !d_split) PT_FAIL(w + ": null argument");
     if (!scene->committed) PT_FAIL(w + ": scene not committed");
     if (camera->res_x <= 0 || camera->res_y <= 0) PT_FAIL(w + ": empty image");
+    if (camera->res_x > 0xFFFF || camera->res_y > 0xFFFF) PT_FAIL(w + ": image larger than 65535 pixels on a side");
     if (sample_begin < 0 || sample_end < sample_begin) PT_FAIL(w + ": bad sample range");
     if (n_split < 1 || n_split > 64) PT_FAIL(w + ": n_split must be in [1,64]");
     if (!is_device_pointer(d_split)) PT_FAIL(w + ": d_split must be a device pointer");

@@ -74,8 +74,8 @@ __device__ __forceinline__ void stats_zero(Stats &s) {
 struct Best {
     float t, bu, bv;
     int32_t entity;    /* -1 = none */
-    int32_t tri;       /* -1 = sphere */
-    uint32_t rec;      /* accepted triangle record: (byte offset of its pair / 16) * 2 + slot */
+    uint32_t rec;      /* accepted triangle record: (byte offset of its pair / 16) * 2 + slot (the triangle's index inside its
+                        * entity is read from the record when the hit is final: best_triangle) */
 };
 
 struct TriLog {        /* optional per-ray record of the triangle-test sequence */
@@ -107,11 +107,15 @@ struct Lane {
     float t0x, t0y, t0z, t1x, t1y, t1z;   /* parametric interval of the current node */
     uint32_t nb;             /* current node: index of its first child */
     uint32_t todo;           /* current node: its child list (see child_list) | child mask << 24 */
-    uint32_t path;           /* 3 bits per level: the child slot taken at each ancestor */
-    int32_t level, maxd, a;
+    uint32_t path;           /* 3 bits per level: the child slot taken at each ancestor, under a leading 1 (1 = at the root);
+                              * 0 while the lane is not inside an octree (sphere, brute-force run) */
+    int32_t rem;             /* levels between the current node's children and the leaves (0: its children are leaves); also
+                              * the slot of the frame its parent pushed */
+    int32_t a;
     /* triangle run (octree leaf or brute-force mesh) */
     uint32_t tri_cur, tri_left;   /* byte offset of the run's next triangle pair, triangles still to test */
-    int32_t run_flags;       /* bit0: some test of this run was accepted, bit1: run is an octree leaf */
+    /* a run that accepted a test shows in best.entity (== ent - 1: an entity is visited once per ray and an octree walk
+     * ends with the first leaf that accepts); a run that is an octree leaf shows in path != 0 */
 };
 
 /*
@@ -190,7 +194,7 @@ __device__ __forceinline__ int next_entity_mode(const PtSceneDev &sc, const Lane
 
 __device__ __forceinline__ void lane_start_ray(Lane &L, V3 o, V3 d) {
     L.o = o; L.d = d;
-    L.best.t = FLT_MAX; L.best.bu = 0.f; L.best.bv = 0.f; L.best.entity = -1; L.best.tri = -1; L.best.rec = 0;
+    L.best.t = FLT_MAX; L.best.bu = 0.f; L.best.bv = 0.f; L.best.entity = -1; L.best.rec = 0;
     L.ent = 0;
     L.mode = M_ENTITY;
 }
@@ -218,7 +222,7 @@ __device__ __forceinline__ void entity_block(const PtSceneDev &sc, Lane &L, Stat
             const float t = p1 - p2 > 0 ? p1 - p2 : p1 + p2;
             if (t > 0 && t < L.best.t) {
                 L.best.t = t; L.best.bu = 0.0f; L.best.bv = 0.0f;
-                L.best.entity = ei; L.best.tri = -1; L.best.rec = 0;
+                L.best.entity = ei; L.best.rec = 0;
             }
         }
         return;
@@ -229,7 +233,7 @@ __device__ __forceinline__ void entity_block(const PtSceneDev &sc, Lane &L, Stat
     if (e.octree_depth == 0) {            /* dgf:286-291 */
         if (e.n_tris == 0) return;
         L.tri_cur = e.tri_first << 4; L.tri_left = e.n_tris;
-        L.run_flags = 0;
+        L.path = 0;
         L.mode = M_LEAF;
         return;
     }
@@ -255,7 +259,7 @@ __device__ __forceinline__ void entity_block(const PtSceneDev &sc, Lane &L, Stat
     const PtNode rec = sc.nodes[e.root_node];
     L.t0x = t0x; L.t0y = t0y; L.t0z = t0z; L.t1x = t1x; L.t1y = t1y; L.t1z = t1z;
     L.nb = rec.a;
-    L.a = a; L.level = 0; L.path = 0; L.maxd = e.octree_depth;
+    L.a = a; L.path = 1u; L.rem = e.octree_depth - 1;
     L.todo = child_list<STATS>(t0x, t0y, t0z, t1x, t1y, t1z, rec.b, a);
     L.mode = M_NODE;
 }
@@ -279,10 +283,10 @@ template <bool STATS>
 __device__ __forceinline__ void node_block(const PtSceneDev &sc, Lane &L, Stats &st, float4 *stack, uint32_t *stack1, int stride) {
     if ((L.todo & 0xFFu) == 0u) {
         if (STATS) st.node_visits += __popc((L.todo >> 8) & 0xFFu);
-        if (L.level == 0) { L.mode = next_entity_mode(sc, L); return; }     /* walk finished without an accepted leaf */
-        L.level--;
-        const float4 s = stack[L.level * stride];
-        const uint32_t w = stack1[L.level * stride];
+        if (L.path == 1u) { L.mode = next_entity_mode(sc, L); return; }     /* walk finished without an accepted leaf */
+        const float4 s = stack[L.rem * stride];
+        const uint32_t w = stack1[L.rem * stride];
+        L.rem++;
         const int c = (int)(L.path & 7u);
         L.path >>= 3;
         /* value selects, not conditional stores: a store through a selected field address would
@@ -308,30 +312,41 @@ __device__ __forceinline__ void node_block(const PtSceneDev &sc, Lane &L, Stats 
     const int adj = curr ^ L.a;
     const uint32_t child = L.nb + (uint32_t)__popc(nm & ((1u << adj) - 1u));
     const PtNode rec = sc.nodes[child];
-    if (L.level + 1 == L.maxd) {          /* leaf: dgf:146-157 */
+    if (L.rem == 0) {                     /* leaf: dgf:146-157 */
         if (rec.b != 0u) {
             L.tri_cur = rec.a << 4; L.tri_left = rec.b;
-            L.run_flags = 2;
             L.mode = M_LEAF;
         }
         return;
     }
-    /* interval of child `curr` */
-    const float c0x = (curr & 4) ? tMx : L.t0x, c1x = (curr & 4) ? L.t1x : tMx;
-    const float c0y = (curr & 2) ? tMy : L.t0y, c1y = (curr & 2) ? L.t1y : tMy;
-    const float c0z = (curr & 1) ? tMz : L.t0z, c1z = (curr & 1) ? L.t1z : tMz;
+    /* interval of child `curr`: per axis the child keeps one bound of the parent and takes tM as the other; the bound it
+     * does not keep goes into the frame.  Written as selects in place on one condition register per axis (three
+     * selects each, the frame word first because it reads the bounds the other two overwrite): left to the compiler
+     * the new interval lands in fresh registers and is copied back and forth to join the lanes that do not descend */
     float4 s;
-    s.x = (curr & 4) ? L.t0x : L.t1x;
-    s.y = (curr & 2) ? L.t0y : L.t1y;
-    s.z = (curr & 1) ? L.t0z : L.t1z;
+    asm("v_cmp_ne_u32_e32 vcc, 0, %[mx]\n\t"
+        "v_cndmask_b32_e32 %[sx], %[t1x], %[t0x], vcc\n\t"
+        "v_cndmask_b32_e32 %[t0x], %[t0x], %[tMx], vcc\n\t"
+        "v_cndmask_b32_e32 %[t1x], %[tMx], %[t1x], vcc\n\t"
+        "v_cmp_ne_u32_e32 vcc, 0, %[my]\n\t"
+        "v_cndmask_b32_e32 %[sy], %[t1y], %[t0y], vcc\n\t"
+        "v_cndmask_b32_e32 %[t0y], %[t0y], %[tMy], vcc\n\t"
+        "v_cndmask_b32_e32 %[t1y], %[tMy], %[t1y], vcc\n\t"
+        "v_cmp_ne_u32_e32 vcc, 0, %[mz]\n\t"
+        "v_cndmask_b32_e32 %[sz], %[t1z], %[t0z], vcc\n\t"
+        "v_cndmask_b32_e32 %[t0z], %[t0z], %[tMz], vcc\n\t"
+        "v_cndmask_b32_e32 %[t1z], %[tMz], %[t1z], vcc"
+        : [sx] "=&v"(s.x), [sy] "=&v"(s.y), [sz] "=&v"(s.z), [t0x] "+v"(L.t0x), [t1x] "+v"(L.t1x), [t0y] "+v"(L.t0y),
+          [t1y] "+v"(L.t1y), [t0z] "+v"(L.t0z), [t1z] "+v"(L.t1z)
+        : [mx] "v"(curr & 4), [my] "v"(curr & 2), [mz] "v"(curr & 1), [tMx] "v"(tMx), [tMy] "v"(tMy), [tMz] "v"(tMz)
+        : "vcc");
     s.w = __uint_as_float(L.nb);
-    stack[L.level * stride] = s;
-    stack1[L.level * stride] = L.todo;
+    asm("v_add_u32_e32 %0, -1, %0" : "+v"(L.rem));               /* in place, like the interval */
+    stack[L.rem * stride] = s;
+    stack1[L.rem * stride] = L.todo;
     L.path = (L.path << 3) | (uint32_t)curr;
-    L.level++;
-    L.t0x = c0x; L.t0y = c0y; L.t0z = c0z; L.t1x = c1x; L.t1y = c1y; L.t1z = c1z;
-    L.nb = rec.a;
-    L.todo = child_list<STATS>(c0x, c0y, c0z, c1x, c1y, c1z, rec.b, L.a);
+    asm("v_mov_b32_e32 %0, %1" : "+v"(L.nb) : "v"(rec.a));
+    L.todo = child_list<STATS>(L.t0x, L.t0y, L.t0z, L.t1x, L.t1y, L.t1z, rec.b, L.a);
 }
 
 /*
@@ -406,9 +421,8 @@ __device__ __forceinline__ void leaf_block(const PtSceneDev &sc, Lane &L, Stats 
     /* the closest hit is carried in locals and written back with value selects: conditional stores
      * into the lane state inside this loop would push the state out of registers */
     float bt = L.best.t, bbu = L.best.bu, bbv = L.best.bv;
-    int32_t btri = L.best.tri, bent = L.best.entity;
+    int32_t bent = L.best.entity;
     uint32_t brec = L.best.rec;
-    int32_t flags = L.run_flags;
     while (pend != 0u) {
         const bool second = !(pend & 1u);
         pend &= second ? ~2u : ~1u;
@@ -418,14 +432,11 @@ __device__ __forceinline__ void leaf_block(const PtSceneDev &sc, Lane &L, Stats 
         const bool acc = !(u < -0.0001f || u > 1.0001f) && !(v < -0.0001f || u + v > 1.0001f) && (t > 0 && t < bt);
         bt = acc ? t : bt; bbu = acc ? u : bbu; bbv = acc ? v : bbv;
         bent = acc ? L.ent - 1 : bent;
-        btri = acc ? (second ? id_b : id_a) : btri;
         brec = acc ? ((idx >> 3) | (second ? 1u : 0u)) : brec;
-        flags = acc ? (flags | 1) : flags;
     }
-    L.best.t = bt; L.best.bu = bbu; L.best.bv = bbv; L.best.tri = btri; L.best.entity = bent; L.best.rec = brec;
-    L.run_flags = flags;
+    L.best.t = bt; L.best.bu = bbu; L.best.bv = bbv; L.best.entity = bent; L.best.rec = brec;
     if (L.tri_left == 0u) {
-        if ((L.run_flags & 2) && !(L.run_flags & 1)) L.mode = M_NODE;
+        if (L.path != 0u && bent != L.ent - 1) L.mode = M_NODE;
         else L.mode = next_entity_mode(sc, L);
     }
 }
@@ -582,14 +593,12 @@ __device__ __forceinline__ void leaf_coop(const PtSceneDev &sc, Lane &L, Stats &
             L.best.bu = C->win[lane][0];
             L.best.bv = C->win[lane][1];
             L.best.entity = L.ent - 1;
-            L.best.tri = reinterpret_cast<const int32_t *>(reinterpret_cast<const char *>(sc.tris) + off)[18u + (oi & 1u)];
             L.best.rec = (off >> 3) | (oi & 1u);
-            L.run_flags |= 1;
         }
         L.tri_cur = my_cur + np * (uint32_t)sizeof(PtTriPair);
         L.tri_left = my_left - min(my_left, 2u * np);
         if (L.tri_left == 0u) {
-            if ((L.run_flags & 2) && !(L.run_flags & 1)) L.mode = M_NODE;
+            if (L.path != 0u && L.best.entity != L.ent - 1) L.mode = M_NODE;
             else L.mode = next_entity_mode(sc, L);
         }
     }
@@ -646,11 +655,17 @@ struct Surface {     /* what shading needs from a hit */
 
 /* position / normal / uv of the accepted hit: the tail of intersect_triangle (dgf:353-361) and of
  * trace() (dgf:208-231), evaluated once for the final hit instead of on every improvement. */
+/* index of the accepted triangle inside its entity, -1 for a sphere (and for no hit) */
+__device__ __forceinline__ int32_t best_triangle(const PtSceneDev &sc, const Best &best) {
+    if (best.entity < 0 || sc.entities[best.entity].shape == PT_SHAPE_SPHERE) return -1;
+    return reinterpret_cast<const int32_t *>(reinterpret_cast<const char *>(sc.tris) + (size_t)(best.rec >> 1) * 16u)[18u + (best.rec & 1u)];
+}
+
 __device__ __forceinline__ void finish_hit(const PtSceneDev &sc, V3 o, V3 d, const Best &best, Surface &sf) {
     const PtEntity &e = sc.entities[best.entity];
     sf.position = o + best.t * d;
     sf.u = best.bu; sf.v = best.bv;
-    if (best.tri < 0) {
+    if (e.shape == PT_SHAPE_SPHERE) {
         sf.normal = normalized(sf.position - mk(e.center[0], e.center[1], e.center[2]));
         return;
     }
@@ -658,7 +673,7 @@ __device__ __forceinline__ void finish_hit(const PtSceneDev &sc, V3 o, V3 d, con
     const V3 e1 = mk(pf[6], pf[8], pf[10]), e2 = mk(pf[12], pf[14], pf[16]);
     sf.normal = normalized(cross3(e1, e2));
     if (e.has_uvs || e.smooth_shading) {
-        const PtShadeRec &sh = sc.shade[e.shade_base + (uint32_t)best.tri];
+        const PtShadeRec &sh = sc.shade[e.shade_base + (uint32_t)reinterpret_cast<const int32_t *>(pf - (best.rec & 1u))[18u + (best.rec & 1u)]];
         const float u = best.bu, v = best.bv;
         const float w = 1.0f - (u + v);
         if (e.has_uvs) {   /* meshes without uvs keep the barycentrics (the reference reads d_uvs[-1]) */

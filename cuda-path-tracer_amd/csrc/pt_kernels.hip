@@ -235,13 +235,13 @@ static constexpr int kDoneQuota = PT_DONE_QUOTA;
 #define PT_LEAF_QUOTA 20
 #endif
 static constexpr int kLeafQuota = PT_LEAF_QUOTA;
-/* The render kernel is built twice: for 5 waves per SIMD (96 registers; the octree walk and the
- * triangle test fit, the path state spills around the shading code) and for 4 (128 registers, almost
- * no spills).  Scenes dominated by traversal gain from the extra waves, scenes dominated by entity
- * set-up and shading lose.  (6 waves / 80 registers: equal on the north-star scene, 4 % slower on
- * the larger meshes; 7 and more spill inside the walk.) */
+/* Waves per SIMD (= resident workgroups per CU) the two builds are compiled for: 4, i.e. 128 registers, with which the
+ * lane state stays in registers through the shading code.  At 5 (96 registers) some 40 words per lane were spilled
+ * and reloaded around every shade / refill round -- over a terabyte of scratch writes per 2048-spp frame -- for no gain
+ * in speed: the kernel is bound by vector issue, which four waves saturate.  Deep octrees leave room for fewer
+ * workgroups (LDS stacks): the heavy build is also instantiated for 3. */
 #ifndef PT_WAVES_HEAVY
-#define PT_WAVES_HEAVY 5
+#define PT_WAVES_HEAVY 4
 #endif
 #ifndef PT_WAVES_LIGHT
 #define PT_WAVES_LIGHT 4
@@ -277,7 +277,7 @@ __global__ void __launch_bounds__(kBlock) trace_kernel(PtSceneDev sc, const floa
                 if (L.best.entity >= 0) {
                     Surface sf;
                     finish_hit(sc, L.o, L.d, L.best, sf);
-                    out.entity = L.best.entity; out.triangle = L.best.tri;
+                    out.entity = L.best.entity; out.triangle = best_triangle(sc, L.best);
                     out.bu = L.best.bu; out.bv = L.best.bv; out.u = sf.u; out.v = sf.v;
                     out.position[0] = sf.position.x; out.position[1] = sf.position.y; out.position[2] = sf.position.z;
                     out.normal[0] = sf.normal.x; out.normal[1] = sf.normal.y; out.normal[2] = sf.normal.z;
@@ -399,9 +399,15 @@ __global__ void __launch_bounds__(kBlock, WAVES) render_kernel(RenderParams P) {
     }
     uint32_t probes = 0;
 
-    /* lane state: the (pixel, slice) it owns, the path it is extending, the ray it is tracing */
-    int pixel = -1, pxy = 0, slice = 0, s_cur = 0, s_end = 0, bounce = 0;
-    bool done = false;          /* no more work for this lane */
+    /* lane state: the (pixel, slice) it owns, the path it is extending, the ray it is tracing.  The small fields share
+     * one register (they are live across the octree walk, where registers are short):
+     *   meta bits 0..15  samples of the slice still to do, the current one included (0: the lane owns no pixel)
+     *        bits 16..21 slice;  bits 22..24 bounce;  bit 25 no more work for this lane;  bit 26 the lane owns a pixel whose
+     *        sum has not been written yet */
+    constexpr uint32_t kLeftMask = 0xFFFFu, kSliceShift = 16u, kBounceShift = 22u, kBounceOne = 1u << kBounceShift,
+                       kBounceMask = 7u << kBounceShift, kDoneBit = 1u << 25, kOwnsBit = 1u << 26;
+    uint32_t meta = 0, pxy = 0;
+    int s_cur = 0;
     V3 accum = mk(0.f, 0.f, 0.f), result = mk(0.f, 0.f, 0.f), atten = mk(1.f, 1.f, 1.f);
     Lane L;
     L.mode = M_IDLE;
@@ -424,11 +430,12 @@ __global__ void __launch_bounds__(kBlock, WAVES) render_kernel(RenderParams P) {
                 Surface sf;
                 finish_hit(P.sc, L.o, L.d, L.best, sf);
                 float xi[4];
-                rng_block((uint32_t)pixel, (uint32_t)s_cur, 1u + (uint32_t)bounce, P.seed, xi);
+                const uint32_t bounce = (meta & kBounceMask) >> kBounceShift;
+                rng_block((pxy >> 16) * (uint32_t)W + (pxy & 0xFFFFu), (uint32_t)s_cur, 1u + bounce, P.seed, xi);
                 V3 o = L.o, d = L.d;
                 shade_hit<STATS>(P.sc, L.best, sf, xi, o, d, atten, result, st);
-                bounce++;
-                ended = bounce >= 6;   /* src/renderer.cu:99 */
+                meta += kBounceOne;
+                ended = bounce + 1u >= 6u;   /* src/renderer.cu:99 */
                 if (!ended) {
                     if (STATS) st.segments++;
                     lane_start_ray(L, o, d);
@@ -437,16 +444,19 @@ __global__ void __launch_bounds__(kBlock, WAVES) render_kernel(RenderParams P) {
             if (ended) {
                 accum = accum + result;
                 s_cur++;
+                meta -= 1u;
                 L.mode = M_IDLE;
             }
         }
         /* ---- lanes without a path: finish their (pixel, slice), take a new one, start the next sample */
-        if (L.mode == M_IDLE && pixel >= 0 && s_cur >= s_end) {
-            float *out = P.partials + 3 * ((size_t)slice * n_pixels + (size_t)pixel);
+        /* (a lane that owns a pixel and is idle has just ended a path) */
+        const bool wants = L.mode == M_IDLE && (meta & (kLeftMask | kDoneBit)) == 0u;
+        if (wants && (meta & kOwnsBit)) {
+            const size_t pixel = (size_t)(pxy >> 16) * (size_t)W + (size_t)(pxy & 0xFFFFu);
+            float *out = P.partials + 3 * ((size_t)((meta >> kSliceShift) & 63u) * n_pixels + pixel);
             out[0] = accum.x; out[1] = accum.y; out[2] = accum.z;
-            pixel = -1;
+            meta &= ~kOwnsBit;
         }
-        const bool wants = L.mode == M_IDLE && !done && pixel < 0;
         const unsigned long long need = __ballot(wants);
         if (need != 0ull) {
             const int n_need = __popcll(need);
@@ -501,33 +511,31 @@ __global__ void __launch_bounds__(kBlock, WAVES) render_kernel(RenderParams P) {
             }
             if (wants) {
                 if (!got) {
-                    done = true;
+                    meta = kDoneBit;
                 } else {
                     const int px = my_px0 + (my_slot & 7), py = my_py0 + (my_slot >> 3);
                     if (px < W && py < H) {
-                        pixel = py * W + px;
-                        pxy = (py << 16) | px;
-                        slice = my_slice;
+                        pxy = ((uint32_t)py << 16) | (uint32_t)px;
                         s_cur = my_s0;
-                        s_end = my_s1;
+                        meta = kOwnsBit | ((uint32_t)my_slice << kSliceShift) | (uint32_t)(my_s1 - my_s0);
                         accum = mk(0.f, 0.f, 0.f);
                     }
                 }
             }
         }
-        if (L.mode == M_IDLE && pixel >= 0 && s_cur < s_end) {
+        if (L.mode == M_IDLE && (meta & kLeftMask) != 0u) {
             float xi[4];
-            rng_block((uint32_t)pixel, (uint32_t)s_cur, 0u, P.seed, xi);
+            rng_block((pxy >> 16) * (uint32_t)W + (pxy & 0xFFFFu), (uint32_t)s_cur, 0u, P.seed, xi);
             V3 o, d;
-            camera_ray(P.cam, P.camk, pxy & 0xFFFF, pxy >> 16, xi, o, d);
+            camera_ray(P.cam, P.camk, (int)(pxy & 0xFFFFu), (int)(pxy >> 16), xi, o, d);
             atten = mk(1.f, 1.f, 1.f);
             result = mk(0.f, 0.f, 0.f);
-            bounce = 0;
+            meta &= ~kBounceMask;
             if (STATS) { st.paths++; st.segments++; }
             lane_start_ray(L, o, d);
         }
         if (__ballot(L.mode != M_IDLE) == 0ull) {
-            if (__ballot(!done) == 0ull) break;      /* every lane is out of work: the grid drains */
+            if (__ballot(!(meta & kDoneBit)) == 0ull) break;      /* every lane is out of work: the grid drains */
             continue;                                /* e.g. lanes that drew an out-of-image slot ask again */
         }
         trace_wave<STATS, false, COOP>(P.sc, L, st, lg, stack, stack1, kBlock, P.done_quota, P.leaf_quota, coop, lane);
@@ -657,15 +665,11 @@ int launch_render(RenderParams p, int n_cu, int max_queues, bool heavy, hipStrea
     p.items_per_queue = (uint32_t)(((uint64_t)p.n_items + (uint64_t)blocks - 1) / (uint64_t)blocks);
     const dim3 grid((unsigned)blocks), block(kBlock);
     if (heavy) {
-        /* deep octrees need so much LDS for their stacks that fewer workgroups fit than the registers of the
-         * 5-wave build allow: the builds for 4 and 3 waves per SIMD then have the larger register budget for
-         * the same residency (dragon-class scene at depth 7, four workgroups per CU: +7 % with 128 registers) */
+        /* deep octrees need so much LDS for their stacks that fewer workgroups fit: the build for 3 waves per SIMD
+         * then has the larger register budget for the same residency */
         if (per_cu >= kWavesHeavy) {
             if (p.stats) hipLaunchKernelGGL((render_kernel<true, kWavesHeavy, true>), grid, block, lds, stream, p);
             else hipLaunchKernelGGL((render_kernel<false, kWavesHeavy, true>), grid, block, lds, stream, p);
-        } else if (per_cu == 4) {
-            if (p.stats) hipLaunchKernelGGL((render_kernel<true, 4, true>), grid, block, lds, stream, p);
-            else hipLaunchKernelGGL((render_kernel<false, 4, true>), grid, block, lds, stream, p);
         } else {
             if (p.stats) hipLaunchKernelGGL((render_kernel<true, 3, true>), grid, block, lds, stream, p);
             else hipLaunchKernelGGL((render_kernel<false, 3, true>), grid, block, lds, stream, p);

@@ -191,7 +191,7 @@ size_t pt_noalloc_max_partial_bytes(void);
 /* Launch choices (no counterpart in the reference).  The render kernel has two launch choices that
  * change how a wave schedules its lanes and nothing a path computes (images are bit-identical under
  * all of them): the kernel build (0 = light: 4 waves per SIMD, every lane tests the triangle runs of
- * its own ray; 1 = heavy: up to 5 waves, fewer registers, and the triangle runs waiting in a wave are
+ * its own ray; 1 = heavy: 4 waves, or 3 where deep octree stacks fill the LDS, and the triangle runs waiting in a wave are
  * tested by all of its 64 lanes together) and the quorum (how many of a wave's 64 lanes must have finished their ray before the wave leaves
  * the geometry blocks to shade and refill them: high where shading dominates, low inside deep
  * trees).  pt_scene_commit picks defaults from the scene; pt_scene_set_launch fixes a choice for

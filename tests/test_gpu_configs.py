@@ -1,8 +1,8 @@
 """GPU parity of the benchmark configurations whose kernel instantiations the small scenes never select.
 
-The render kernel's heavy build (cooperative leaf phase) is instantiated for 5, 4 and 3 waves per SIMD; which
-one runs follows from the scene (>= 64 k triangle pairs -> heavy) and the octree depth (LDS stacks: depth <= 6
--> 5 waves, 7-8 -> 4, 9-10 -> 3).  Every case here builds a scene large enough that pt_scene_commit picks the
+The render kernel's heavy build (cooperative leaf phase) is instantiated for 4 and 3 waves per SIMD; which
+one runs follows from the scene (>= 64 k triangle pairs -> heavy) and the octree depth (LDS stacks: depth <= 7
+-> 4 waves, deeper -> 3).  Every case here builds a scene large enough that pt_scene_commit picks the
 heavy build BY ITSELF, checks which instantiation runs, and compares with the CPU oracle:
   * pt_trace_rays on camera rays and on secondary rays leaving the first hits: entity / triangle / t /
     barycentrics / uv / position / normal bit-exact, triangle-test order and work counters identical;
@@ -61,7 +61,7 @@ def _check_render(pt, g, cam_g, c, cam_c, res, spp):
 
 CASES = {
     # name: (builder kwargs, waves per SIMD the heavy build must be instantiated for, quorum picked at commit)
-    "hcandersen-5wave": (dict(kind="hcandersen", n_tris=60000, octree_depth=6, tex_res=256, hdri_res=(512, 256)), 5, 48),
+    "hcandersen-4wave": (dict(kind="hcandersen", n_tris=60000, octree_depth=6, tex_res=256, hdri_res=(512, 256)), 4, 48),
     "dragon-4wave": (dict(kind="dragon", n_tris=140000, octree_depth=7, hdri_res=(512, 256)), 4, 40),
     "synthetic-3wave": (dict(kind="synthetic", n_tris=80000, octree_depth=9, hdri_res=(512, 256)), 3, 40),
 }
