@@ -624,10 +624,14 @@ __device__ __forceinline__ void trace_wave(const PtSceneDev &sc, Lane &L, Stats 
         /* a cooperative leaf phase serves every waiting run with all 64 lanes: it runs as soon as `leaf_quota`
          * runs wait (about enough pairs for a full trip), and the walk stops for it */
         const bool leaf_first = COOP ? (n_leaf >= leaf_quota || n_leaf > n_node) : (n_leaf > n_node);
-        if (n_ent >= n_node && n_ent >= n_leaf) {
+        /* one of three blocks runs; written as three independent conditionals (not an if / else-if chain): every block
+         * then is a plain divergent region that updates the lane state in place */
+        const int which = (n_ent >= n_node && n_ent >= n_leaf) ? 0 : (!leaf_first ? 1 : 2);
+        if (which == 0) {
             if (STATS) st.ent_trips++;
             if (L.mode == M_ENTITY) { if (STATS) st.ent_lanes++; entity_block<STATS>(sc, L, st); }
-        } else if (!leaf_first) {
+        }
+        if (which == 1) {
             int trips = 0;
 #pragma nounroll
             do {
@@ -635,15 +639,18 @@ __device__ __forceinline__ void trace_wave(const PtSceneDev &sc, Lane &L, Stats 
                 if (L.mode == M_NODE) { if (STATS) st.node_lanes++; node_block<STATS>(sc, L, st, stack, stack1, stride); }
             } while (++trips < PT_TRIPS && PT_KEEP_NODE * __popcll(__ballot(L.mode == M_NODE)) >= n_node &&
                      !(COOP && __popcll(__ballot(L.mode == M_LEAF)) >= leaf_quota));
-        } else if (COOP) {
-            leaf_coop<STATS>(sc, L, st, coop, lane);
-        } else {
-            int trips = 0;
+        }
+        if (which == 2) {
+            if (COOP) {
+                leaf_coop<STATS>(sc, L, st, coop, lane);
+            } else {
+                int trips = 0;
 #pragma nounroll
-            do {
-                if (STATS) st.leaf_trips++;
-                if (L.mode == M_LEAF) { if (STATS) st.leaf_lanes++; leaf_block<STATS, LOG>(sc, L, st, lg); }
-            } while (++trips < PT_TRIPS && PT_KEEP_LEAF * __popcll(__ballot(L.mode == M_LEAF)) >= n_leaf);
+                do {
+                    if (STATS) st.leaf_trips++;
+                    if (L.mode == M_LEAF) { if (STATS) st.leaf_lanes++; leaf_block<STATS, LOG>(sc, L, st, lg); }
+                } while (++trips < PT_TRIPS && PT_KEEP_LEAF * __popcll(__ballot(L.mode == M_LEAF)) >= n_leaf);
+            }
         }
     }
 }
