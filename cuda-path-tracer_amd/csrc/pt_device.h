@@ -111,6 +111,7 @@ struct Lane {
                               * 0 while the lane is not inside an octree (sphere, brute-force run) */
     int32_t rem;             /* levels between the current node's children and the leaves (0: its children are leaves); also
                               * the slot of the frame its parent pushed */
+    uint32_t framed;         /* bit s: slot s holds a frame (a node with members left); see node_block */
     int32_t a;
     /* triangle run (octree leaf or brute-force mesh) */
     uint32_t tri_cur, tri_left;   /* byte offset of the run's next triangle pair, triangles still to test */
@@ -259,7 +260,7 @@ __device__ __forceinline__ void entity_block(const PtSceneDev &sc, Lane &L, Stat
     const PtNode rec = sc.nodes[e.root_node];
     L.t0x = t0x; L.t0y = t0y; L.t0z = t0z; L.t1x = t1x; L.t1y = t1y; L.t1z = t1z;
     L.nb = rec.a;
-    L.a = a; L.path = 1u; L.rem = e.octree_depth - 1;
+    L.a = a; L.path = 1u; L.framed = 0u; L.rem = e.octree_depth - 1;
     L.todo = child_list<STATS>(t0x, t0y, t0z, t1x, t1y, t1z, rec.b, a);
     L.mode = M_NODE;
 }
@@ -267,37 +268,71 @@ __device__ __forceinline__ void entity_block(const PtSceneDev &sc, Lane &L, Stat
 /*
  * NODE block: proc_subtree's child loop (dgf:159-188) at the current inner node, one entered child
  * per trip.
- *   list exhausted  -> return to the parent (pop), or finish the walk at the root; the parent's
- *                      next child is taken in the same trip;
+ *   list exhausted  -> return to the nearest ancestor that still has members (pop), or finish the walk;
+ *                      that ancestor's next child is taken in the same trip;
  *   next member     -> the child is entered: at leaf depth it becomes a triangle run, otherwise the
- *                      frame is pushed, the walk descends and the child's own list is built.
+ *                      walk descends and the child's own list is built.
  * Members that do not exist cost nothing; members that fail the entry test are counted when the
  * walk passes over them.
- * Frames: descending, each axis of the child interval inherits one bound from the parent
- * ([t0,tM] or [tM,t1]); the frame keeps the three bounds the child does NOT inherit, the parent's
- * first-child index and what is left of its list; the slot taken goes into `path`.  Returning, the
- * parent's t0/t1 are rebuilt from the child's interval and the saved bounds by copies only, and tM
- * is recomputed by the same expression, so every value is the one the recursion would hold.
+ *
+ * Frames.  Descending, each axis of the child interval inherits one bound from the parent ([t0,tM] or
+ * [tM,t1]).  Every node with inner children owns the stack slot of its level (slot = rem - 1), and every
+ * descent writes it:
+ *   - the node has members left (a FRAME): the three bounds the child does not inherit, the node's first-child
+ *     index and the rest of its list; the child taken is appended to `path`, the slot's bit is set in `framed`;
+ *   - the member taken is the node's last one (nothing would be left to do on return: a third of all returns
+ *     used to be of this kind, each a trip of its own): no frame; the slot gets the three bounds of the node's
+ *     OWN interval on the sides it inherited from its parent, and its `framed` bit is cleared.
+ * Returning from an exhausted node goes straight to the nearest ancestor A with a frame: A's interval is its
+ * frame's three bounds plus, on the other sides, the bounds of A's child on the way down -- which is the
+ * exhausted node itself, or else a node that descended without a frame and left exactly those bounds in its slot.
+ * Copies only; tM is recomputed by the same expression, so every value is the one the recursion would hold.
+ * (A counting build keeps a frame while rejected members are left to count, and may find a frame without members
+ * on return: it then returns again in its next trip.)
  */
 template <bool STATS>
 __device__ __forceinline__ void node_block(const PtSceneDev &sc, Lane &L, Stats &st, float4 *stack, uint32_t *stack1, int stride) {
     if ((L.todo & 0xFFu) == 0u) {
         if (STATS) st.node_visits += __popc((L.todo >> 8) & 0xFFu);
-        if (L.path == 1u) { L.mode = next_entity_mode(sc, L); return; }     /* walk finished without an accepted leaf */
-        const float4 s = stack[L.rem * stride];
-        const uint32_t w = stack1[L.rem * stride];
-        L.rem++;
-        const int c = (int)(L.path & 7u);
+        const uint32_t above = L.framed >> L.rem;              /* bit 0: the parent's slot */
+        if (above == 0u) { L.mode = next_entity_mode(sc, L); return; }     /* walk finished without an accepted leaf */
+        const int up = __builtin_ctz(above);
+        const int slot = L.rem + up;
+        const float4 s = stack[slot * stride];
+        const uint32_t w = stack1[slot * stride];
+        const float4 h = stack[(slot > 0 ? slot - 1 : 0) * stride];        /* read by lanes with up > 0 only */
+        const uint32_t c = L.path & 7u;
         L.path >>= 3;
-        /* value selects, not conditional stores: a store through a selected field address would
-         * force the whole lane state into scratch memory */
-        const float p0x = (c & 4) ? s.x : L.t0x, p1x = (c & 4) ? L.t1x : s.x;
-        const float p0y = (c & 2) ? s.y : L.t0y, p1y = (c & 2) ? L.t1y : s.y;
-        const float p0z = (c & 1) ? s.z : L.t0z, p1z = (c & 1) ? L.t1z : s.z;
-        L.t0x = p0x; L.t1x = p1x; L.t0y = p0y; L.t1y = p1y; L.t0z = p0z; L.t1z = p1z;
+        /* per axis: k = the bound the frame's owner shares with its child on the way down (the child's t1 where the
+         * child is an upper half, else its t0) -- taken from this node if the frame is its parent's (bit 0 of `above`),
+         * else from the slot below the frame; then owner.t0 = upper half ? frame word : k, owner.t1 = upper half ? k :
+         * frame word.  Bitwise selects on 0 / ~0 masks, in place. */
+        {
+            uint32_t direct, cm, k;
+            asm("v_bfe_i32 %[direct], %[above], 0, 1\n\t"
+                "v_bfe_i32 %[cm], %[c], 2, 1\n\t"
+                "v_bitop3_b32 %[k], %[cm], %[t1x], %[t0x] bitop3:0xca\n\t"
+                "v_bitop3_b32 %[k], %[direct], %[k], %[hx] bitop3:0xca\n\t"
+                "v_bitop3_b32 %[t0x], %[cm], %[sx], %[k] bitop3:0xca\n\t"
+                "v_bitop3_b32 %[t1x], %[cm], %[k], %[sx] bitop3:0xca\n\t"
+                "v_bfe_i32 %[cm], %[c], 1, 1\n\t"
+                "v_bitop3_b32 %[k], %[cm], %[t1y], %[t0y] bitop3:0xca\n\t"
+                "v_bitop3_b32 %[k], %[direct], %[k], %[hy] bitop3:0xca\n\t"
+                "v_bitop3_b32 %[t0y], %[cm], %[sy], %[k] bitop3:0xca\n\t"
+                "v_bitop3_b32 %[t1y], %[cm], %[k], %[sy] bitop3:0xca\n\t"
+                "v_bfe_i32 %[cm], %[c], 0, 1\n\t"
+                "v_bitop3_b32 %[k], %[cm], %[t1z], %[t0z] bitop3:0xca\n\t"
+                "v_bitop3_b32 %[k], %[direct], %[k], %[hz] bitop3:0xca\n\t"
+                "v_bitop3_b32 %[t0z], %[cm], %[sz], %[k] bitop3:0xca\n\t"
+                "v_bitop3_b32 %[t1z], %[cm], %[k], %[sz] bitop3:0xca"
+                : [direct] "=&v"(direct), [cm] "=&v"(cm), [k] "=&v"(k), [t0x] "+v"(L.t0x), [t1x] "+v"(L.t1x), [t0y] "+v"(L.t0y),
+                  [t1y] "+v"(L.t1y), [t0z] "+v"(L.t0z), [t1z] "+v"(L.t1z)
+                : [above] "v"(above), [c] "v"(c), [sx] "v"(s.x), [sy] "v"(s.y), [sz] "v"(s.z), [hx] "v"(h.x), [hy] "v"(h.y), [hz] "v"(h.z));
+        }
+        L.rem = slot + 1;
         L.nb = __float_as_uint(s.w);
         L.todo = w;
-        if ((w & 0xFFu) == 0u) return;                       /* the parent is exhausted as well: next trip */
+        if (STATS && (w & 0xFFu) == 0u) return;               /* only rejected members were left: counted in the next trip */
     }
     const int curr = __builtin_ctz(L.todo);                   /* lowest go bit = next member (go != 0 here) */
     if (STATS) {
@@ -319,32 +354,40 @@ __device__ __forceinline__ void node_block(const PtSceneDev &sc, Lane &L, Stats 
         }
         return;
     }
-    /* interval of child `curr`: per axis the child keeps one bound of the parent and takes tM as the other; the bound it
-     * does not keep goes into the frame.  Written as selects in place on one condition register per axis (three
-     * selects each, the frame word first because it reads the bounds the other two overwrite): left to the compiler
-     * the new interval lands in fresh registers and is copied back and forth to join the lanes that do not descend */
+    const bool last = (L.todo & 0xFFFFu) == 0u;              /* nothing left at this node: no frame */
+    /* which bound of each axis goes into the slot: frame -> the one the child does not inherit (t0 where it takes
+     * the upper half); no frame -> the one this node inherited from its parent (t1 where IT is an upper half: the last
+     * digit of `path`, which is the parent's if the parent has a frame; otherwise nobody reads the slot) */
+    const uint32_t pick = last ? (L.path & 7u) : ~(uint32_t)curr;
     float4 s;
-    asm("v_cmp_ne_u32_e32 vcc, 0, %[mx]\n\t"
-        "v_cndmask_b32_e32 %[sx], %[t1x], %[t0x], vcc\n\t"
+    asm("v_add_u32_e32 %0, -1, %0" : "+v"(L.rem));               /* in place, like the interval below */
+    const uint32_t bit = 1u << L.rem;
+    L.framed = last ? (L.framed & ~bit) : (L.framed | bit);
+    /* the child's interval, selected in place (left to the compiler it lands in fresh registers and is copied back and
+     * forth to join the lanes that do not descend); the slot words first: they read the bounds the others overwrite */
+    asm("v_bfe_i32 %[sx], %[pick], 2, 1\n\t"
+        "v_bfe_i32 %[sy], %[pick], 1, 1\n\t"
+        "v_bfe_i32 %[sz], %[pick], 0, 1\n\t"
+        "v_bitop3_b32 %[sx], %[sx], %[t1x], %[t0x] bitop3:0xca\n\t"
+        "v_bitop3_b32 %[sy], %[sy], %[t1y], %[t0y] bitop3:0xca\n\t"
+        "v_bitop3_b32 %[sz], %[sz], %[t1z], %[t0z] bitop3:0xca\n\t"
+        "v_cmp_ne_u32_e32 vcc, 0, %[mx]\n\t"
         "v_cndmask_b32_e32 %[t0x], %[t0x], %[tMx], vcc\n\t"
         "v_cndmask_b32_e32 %[t1x], %[tMx], %[t1x], vcc\n\t"
         "v_cmp_ne_u32_e32 vcc, 0, %[my]\n\t"
-        "v_cndmask_b32_e32 %[sy], %[t1y], %[t0y], vcc\n\t"
         "v_cndmask_b32_e32 %[t0y], %[t0y], %[tMy], vcc\n\t"
         "v_cndmask_b32_e32 %[t1y], %[tMy], %[t1y], vcc\n\t"
         "v_cmp_ne_u32_e32 vcc, 0, %[mz]\n\t"
-        "v_cndmask_b32_e32 %[sz], %[t1z], %[t0z], vcc\n\t"
         "v_cndmask_b32_e32 %[t0z], %[t0z], %[tMz], vcc\n\t"
         "v_cndmask_b32_e32 %[t1z], %[tMz], %[t1z], vcc"
         : [sx] "=&v"(s.x), [sy] "=&v"(s.y), [sz] "=&v"(s.z), [t0x] "+v"(L.t0x), [t1x] "+v"(L.t1x), [t0y] "+v"(L.t0y),
           [t1y] "+v"(L.t1y), [t0z] "+v"(L.t0z), [t1z] "+v"(L.t1z)
-        : [mx] "v"(curr & 4), [my] "v"(curr & 2), [mz] "v"(curr & 1), [tMx] "v"(tMx), [tMy] "v"(tMy), [tMz] "v"(tMz)
+        : [pick] "v"(pick), [mx] "v"(curr & 4), [my] "v"(curr & 2), [mz] "v"(curr & 1), [tMx] "v"(tMx), [tMy] "v"(tMy), [tMz] "v"(tMz)
         : "vcc");
     s.w = __uint_as_float(L.nb);
-    asm("v_add_u32_e32 %0, -1, %0" : "+v"(L.rem));               /* in place, like the interval */
     stack[L.rem * stride] = s;
     stack1[L.rem * stride] = L.todo;
-    L.path = (L.path << 3) | (uint32_t)curr;
+    L.path = last ? L.path : ((L.path << 3) | (uint32_t)curr);
     asm("v_mov_b32_e32 %0, %1" : "+v"(L.nb) : "v"(rec.a));
     L.todo = child_list<STATS>(L.t0x, L.t0y, L.t0z, L.t1x, L.t1y, L.t1z, rec.b, L.a);
 }
