@@ -35,8 +35,11 @@ __device__ __forceinline__ CoopLds *coop_area(float4 *lds, int max_depth) {
 
 /* ------------------------------------------------------------------ shading (fast math allowed) */
 /* The library is built with -ffp-contract=off because geometry must round like a scalar IEEE evaluation.  Shading is
- * compared with the reference by tolerance, so its functions let the compiler fuse multiply-adds (PT_SHADING_FP). */
-#define PT_SHADING_FP _Pragma("clang fp contract(fast)")
+ * compared with the reference by tolerance, so its functions fuse a multiply with the add it feeds WITHIN one expression
+ * (contract(on): decided by the front end from the source text alone.  contract(fast) lets the optimiser fuse across
+ * statements depending on how often a product is used, which differs between the instantiations of the render kernel:
+ * their images must be bit-identical). */
+#define PT_SHADING_FP _Pragma("clang fp contract(on)")
 
 __device__ __forceinline__ float fast_rsq(float x) { return __builtin_amdgcn_rsqf(x); }
 __device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
@@ -425,29 +428,15 @@ __global__ void __launch_bounds__(kBlock, WAVES) render_kernel(RenderParams P) {
     for (;;) {
         /* ---- shade the lanes whose ray is finished (color()'s loop body, src/renderer.cu:99-139) */
         if (STATS) st.front_trips++;
+        /* a finished ray that hit nothing takes the environment and ends its path here; one that hit something is
+         * shaded further down, after the refill, so that the random numbers of both kinds of lane -- the shading block of
+         * a hit, the camera block of a new path -- come from one evaluation of the generator */
+        const bool hit = L.mode == M_DONE && L.best.entity >= 0;
         if (L.mode == M_DONE) {
             if (STATS) st.front_lanes++;
-            bool ended;
-            if (L.best.entity < 0) {
+            if (!hit) {
                 const V3 env = sample_hdri<STATS>(P.sc, L.d, st);
                 result = result + atten * env;
-                ended = true;
-            } else {
-                Surface sf;
-                finish_hit(P.sc, L.o, L.d, L.best, sf);
-                float xi[4];
-                const uint32_t bounce = (meta & kBounceMask) >> kBounceShift;
-                rng_block((pxy >> 16) * (uint32_t)W + (pxy & 0xFFFFu), (uint32_t)s_cur, 1u + bounce, P.seed, xi);
-                V3 o = L.o, d = L.d;
-                shade_hit<STATS>(P.sc, L.best, sf, xi, o, d, atten, result, st);
-                meta += kBounceOne;
-                ended = bounce + 1u >= 6u;   /* src/renderer.cu:99 */
-                if (!ended) {
-                    if (STATS) st.segments++;
-                    lane_start_ray(L, o, d);
-                }
-            }
-            if (ended) {
                 accum = accum + result;
                 s_cur++;
                 meta -= 1u;
@@ -529,16 +518,35 @@ __global__ void __launch_bounds__(kBlock, WAVES) render_kernel(RenderParams P) {
                 }
             }
         }
-        if (L.mode == M_IDLE && (meta & kLeftMask) != 0u) {
+        const bool start = L.mode == M_IDLE && (meta & kLeftMask) != 0u;
+        if (hit || start) {
             float xi[4];
-            rng_block((pxy >> 16) * (uint32_t)W + (pxy & 0xFFFFu), (uint32_t)s_cur, 0u, P.seed, xi);
-            V3 o, d;
-            camera_ray(P.cam, P.camk, (int)(pxy & 0xFFFFu), (int)(pxy >> 16), xi, o, d);
-            atten = mk(1.f, 1.f, 1.f);
-            result = mk(0.f, 0.f, 0.f);
-            meta &= ~kBounceMask;
-            if (STATS) { st.paths++; st.segments++; }
-            lane_start_ray(L, o, d);
+            const uint32_t bounce = (meta & kBounceMask) >> kBounceShift;
+            rng_block((pxy >> 16) * (uint32_t)W + (pxy & 0xFFFFu), (uint32_t)s_cur, hit ? 1u + bounce : 0u, P.seed, xi);
+            if (hit) {
+                Surface sf;
+                finish_hit(P.sc, L.o, L.d, L.best, sf);
+                V3 o = L.o, d = L.d;
+                shade_hit<STATS>(P.sc, L.best, sf, xi, o, d, atten, result, st);
+                meta += kBounceOne;
+                if (bounce + 1u >= 6u) {   /* src/renderer.cu:99; the lane's next sample starts in the next round */
+                    accum = accum + result;
+                    s_cur++;
+                    meta -= 1u;
+                    L.mode = M_IDLE;
+                } else {
+                    if (STATS) st.segments++;
+                    lane_start_ray(L, o, d);
+                }
+            } else {
+                V3 o, d;
+                camera_ray(P.cam, P.camk, (int)(pxy & 0xFFFFu), (int)(pxy >> 16), xi, o, d);
+                atten = mk(1.f, 1.f, 1.f);
+                result = mk(0.f, 0.f, 0.f);
+                meta &= ~kBounceMask;
+                if (STATS) { st.paths++; st.segments++; }
+                lane_start_ray(L, o, d);
+            }
         }
         if (__ballot(L.mode != M_IDLE) == 0ull) {
             if (__ballot(!(meta & kDoneBit)) == 0ull) break;      /* every lane is out of work: the grid drains */
