@@ -237,6 +237,12 @@ def main():
            "traffic_frac": round(traffic / k_s / 1e9 / HBM_PEAK_GBPS, 4) if traffic and k_ms > 0 else None,
            "write_amplification": round(write_b / partial_bytes, 2) if write_b else None,
            "traffic_source": "profiles/r2/traffic.json" if tj else None}
+    fj = stamped_profile("fetch_by_array.json", workload_name, world)
+    if fj and k_ms > 0:
+        # which array the memory-side fetches belong to (probe builds that keep one array in cache): the octree's nodes and
+        # triangle records are in "geometry_and_scratch" together with the reloads of spilled registers
+        hbm["fetch_GBps_by_array"] = {k: round(fj[k] / k_s / 1e9, 1) for k in ("textures", "hdri", "geometry_and_scratch")}
+        hbm["fetch_by_array_source"] = "profiles/r2/fetch_by_array.json"
     # (d) what binds: vector-instruction issue.  frac = (share of the time the SIMDs' vector units are busy) x (mean share
     # of the 64 lanes active in a vector instruction) = share of the chip's lane slots that do work
     n_mesh = sum(1 for e in desc["entities"] if e["kind"] == "mesh")

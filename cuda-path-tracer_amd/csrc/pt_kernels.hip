@@ -66,6 +66,9 @@ __device__ __forceinline__ float luminosity(V3 c) {
     PT_SHADING_FP
     return c.x * 0.2126f + c.y * 0.7152f + c.z * 0.0722f; }  /* src/util.cuh:40 */
 
+/* Traffic probes (profiles/fetch_attr.sh): builds that read texel 0 of every texture (PT_PROBE_TEXEL0) or of the
+ * environment map (PT_PROBE_HDRI0) instead of the addressed one -- same instructions, same paths through the scene up to
+ * the colours, but the array stays in cache: the drop in memory-side fetch bytes is that array's share.  Not renders. */
 __device__ __forceinline__ int to_index(float f, int n) {   /* C truncation, clamped into the image */
     if (!(f >= 0.0f)) return 0;
     if (f >= (float)n) return n - 1;
@@ -75,15 +78,21 @@ __device__ __forceinline__ int to_index(float f, int n) {   /* C truncation, cla
 
 /* src/texture.cuh:22-43 (indices clamped into the texture) */
 __device__ __forceinline__ V3 tex_rgb(const uint8_t *data, int w, int h, float u, float v) {
-    const int x = to_index(u * (float)w, w);
-    const int y = to_index((1.0f - v) * (float)h, h);
+    int x = to_index(u * (float)w, w);
+    int y = to_index((1.0f - v) * (float)h, h);
+#ifdef PT_PROBE_TEXEL0
+    x = 0; y = 0;
+#endif
     const uint8_t *p = data + 3 * ((size_t)y * (size_t)w + (size_t)x);
     const float k = 1.0f / 255.0f;
     return mk((float)p[0] * k, (float)p[1] * k, (float)p[2] * k);
 }
 __device__ __forceinline__ float tex_gray(const uint8_t *data, int w, int h, float u, float v) {
-    const int x = to_index(u * (float)w, w);
-    const int y = to_index((1.0f - v) * (float)h, h);
+    int x = to_index(u * (float)w, w);
+    int y = to_index((1.0f - v) * (float)h, h);
+#ifdef PT_PROBE_TEXEL0
+    x = 0; y = 0;
+#endif
     return (float)data[(size_t)y * (size_t)w + (size_t)x] * (1.0f / 255.0f);
 }
 
@@ -93,13 +102,17 @@ __device__ __forceinline__ V3 sample_hdri(const PtSceneDev &sc, V3 v, Stats &st)
     PT_SHADING_FP
     if (!sc.has_hdri) return mk(0.f, 0.f, 0.f);
     if (STATS) st.env_lookups++;
-    const int W = sc.hdri_w, H = sc.hdri_h;
     const float rn = fast_rsq(v.x * v.x + v.z * v.z);
     const float vpx = v.x * rn, vpz = v.z * rn;
     float x_c = ((acosf(vpz) * ((__float_as_uint(vpx) >> 31) ? -1.0f : 1.0f)) * (1.0f / (2.0f * 3.14159265f))) + 0.5f;
     const float y_c = fminf(1.0f - ((v.y + 1.0f) * 0.5f), 0.99f);
     x_c += sc.hdri_rot_offset;
     x_c = __builtin_amdgcn_fractf(x_c);      /* fmodf(x, 1) for x >= 0: both are exact */
+#ifdef PT_PROBE_HDRI0
+    const int W = 2, H = 2;
+#else
+    const int W = sc.hdri_w, H = sc.hdri_h;
+#endif
     const float *cols = sc.hdri;
     V3 res;
     if (!sc.use_smooth_hdri) {

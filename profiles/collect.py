@@ -103,3 +103,8 @@ for line in open(f"{out}/kernel_stats_{tag}.csv"):
 for d in cfgs:
     print(d["config"]["workload"], d["value"], d["roofline"]["kernel_ms"], d["roofline"]["frac"], d["post_chain_ms"], d["scene_build_upload_s"], d["launch"])
 print("traced bench", bench["value"], bench["roofline"]["kernel_ms"])
+
+# memory-side fetch bytes by array (profiles/fetch_attr.sh <tag>), if that run exists
+fa = os.path.join(root, "gpurun_out", f"fetch_{tag}", "fetch_by_array.json")
+if os.path.exists(fa):
+    shutil.copy(fa, f"{out}/fetch_by_array.json")
