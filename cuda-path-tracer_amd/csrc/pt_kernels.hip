@@ -223,20 +223,19 @@ __device__ __forceinline__ void shade_hit(const PtSceneDev &sc, const Best &best
     diff_chance *= rsum;
     const float roulette = xi[0];
     o = sf.position + 0.001f * normal;
-    if (roulette < spec_chance) {
-        const float alpha = __builtin_amdgcn_exp2f(smoothness * smoothness * 9.965784284662087f);   /* 1000^(s^2) */
-        const float dn = dot3(d, normal);
-        const V3 refl = d - (2.0f * dn) * normal;                                                   /* renderer.cu:147-149 */
-        d = sample_hemisphere(refl, alpha, xi[1], xi[2]);
-        const float f = (alpha + 2.0f) * fast_rcp(alpha + 1.0f);
-        const float k = fast_rcp(spec_chance) * f * dot3(normal, d);
-        atten = mk(atten.x * specular.x * k, atten.y * specular.y * k, atten.z * specular.z * k);
-    } else {
-        result = result + emission * (albedo * atten);
-        d = sample_hemisphere(normal, 1.0f, xi[1], xi[2]);
-        const float k = fast_rcp(diff_chance);
-        atten = mk(atten.x * albedo.x * k, atten.y * albedo.y * k, atten.z * albedo.z * k);
-    }
+    /* the two outcomes of the roulette (src/renderer.cu:117-137) differ in the lobe that is sampled -- around the mirror
+     * direction with exponent 1000^(s^2), or around the normal with exponent 1 -- and in the weight: the lobe's axis and
+     * exponent are selected first, so that the sampling code runs once for the lanes of both outcomes */
+    const bool spec = roulette < spec_chance;
+    const float dn = dot3(d, normal);
+    const V3 refl = d - (2.0f * dn) * normal;                                                       /* renderer.cu:147-149 */
+    const V3 axis = spec ? refl : normal;
+    const float alpha = spec ? __builtin_amdgcn_exp2f(smoothness * smoothness * 9.965784284662087f) : 1.0f;   /* 1000^(s^2) */
+    if (!spec) result = result + emission * (albedo * atten);
+    d = sample_hemisphere(axis, alpha, xi[1], xi[2]);
+    const V3 tint = spec ? specular : albedo;
+    const float k = spec ? fast_rcp(spec_chance) * ((alpha + 2.0f) * fast_rcp(alpha + 1.0f)) * dot3(normal, d) : fast_rcp(diff_chance);
+    atten = mk(atten.x * tint.x * k, atten.y * tint.y * k, atten.z * tint.z * k);
 }
 
 /* counters: reduce over the wave, one atomic per wave and counter */
