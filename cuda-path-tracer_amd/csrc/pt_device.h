@@ -140,13 +140,16 @@ template <bool STATS>
 __device__ __forceinline__ uint32_t child_list(float t0x, float t0y, float t0z, float t1x, float t1y, float t1z, uint32_t nm,
                                                int a) {
     const float tMx = 0.5f * (t0x + t1x), tMy = 0.5f * (t0y + t1y), tMz = 0.5f * (t0z + t1z);
-    /* find_first_node; the state of the walk is kept as one flag per axis (its bit in the child
-     * number) and that axis' exit parameter (t1 once the bit is set, tM before), so that a step is
-     * three comparisons and three selects; the flag logic is wave-uniform-style mask arithmetic */
-    const bool fx = (t0x > t0y) && (t0x > t0z);
-    const bool fy = !fx && (t0y > t0z);
-    const float te = fx ? t0x : (fy ? t0y : t0z);
-    bool bx = !fx && (tMx < te), by = (fx || !fy) && (tMy < te), bz = (fx || fy) && (tMz < te);
+    /* find_first_node (dgf:95-110): the entry plane is the one with the largest t0, and every OTHER axis whose mid plane
+     * lies before the entry point te starts with its bit set.  The entry axis needs no special case: its own mid
+     * parameter cannot lie before te = its t0, because t0 <= t1 on every axis (the ray was mirrored to run along
+     * +x +y +z) and 0.5 * (t0 + t1) rounds monotonically, so tM >= t0; with ties for the largest t0 the tied axes all
+     * have tM >= te.  So: te = max(t0), bit = tM < te on all three axes.
+     * The state of the walk is then one flag per axis (its bit in the child number) and that axis' exit parameter
+     * (t1 once the bit is set, tM before), so that a step is three comparisons and three selects; the flag logic is
+     * mask arithmetic on the scalar unit */
+    const float te = fmaxf(fmaxf(t0x, t0y), t0z);
+    bool bx = tMx < te, by = tMy < te, bz = tMz < te;
     float ex = bx ? t1x : tMx, ey = by ? t1y : tMy, ez = bz ? t1z : tMz;
     uint32_t c = (bx ? 4u : 0u) | (by ? 2u : 0u) | (bz ? 1u : 0u);
     uint32_t list = nm << 24;
