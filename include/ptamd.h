@@ -200,8 +200,8 @@ size_t pt_noalloc_max_partial_bytes(void);
 int pt_scene_set_launch(pt_scene *scene, int kernel_build, int quorum);
 int pt_scene_get_launch(pt_scene *scene, int *kernel_build, int *quorum);
 /* 256-thread workgroups of the render kernel resident per CU for the committed scene = waves per SIMD =
- * the register budget the kernel was instantiated for: the heavy build runs 5 (96 registers), or 4 (128) /
- * 3 (168) when the LDS stacks of a deep octree (depth 7-8 / 9-10) leave room for no more; the light build 4. */
+ * the register budget the kernel was instantiated for: both builds run 4 (128 registers); the heavy build 3 (168)
+ * when the LDS stacks of a deep octree (depth 8 and more) leave room for no more. */
 int pt_scene_render_residency(pt_scene *scene, int *workgroups_per_cu);
 /* Measurement aid (no counterpart in the reference): when enabled, every pt_render_accumulate
  * brackets its path-tracing kernel with two HIP events on the launch stream;
