@@ -103,6 +103,7 @@ struct Lane {
     Best best;
     int32_t mode;
     int32_t ent;             /* entity being processed (M_ENTITY: about to start it) */
+    uint32_t emask;          /* builds with the entity pre-pass: bit e = entity e is still worth a visit */
     /* octree walk */
     float t0x, t0y, t0z, t1x, t1y, t1z;   /* parametric interval of the current node */
     uint32_t nb;             /* current node: index of its first child */
@@ -191,8 +192,19 @@ __device__ __forceinline__ bool slab_test(const float mn[3], const float mx[3], 
     return !(tmax < 0.0f || tmin > tmax || best_t < tmin);
 }
 
+/* The entity pre-pass (builds for scenes of many small entities: PREPASS) tests the boxes of all mesh entities against a
+ * fresh ray in one uniform loop and leaves the set of entities worth a visit in L.emask: spheres, and meshes whose box the
+ * ray does not miss.  The tests use an infinite closest distance, so they pass a superset of what the walk-time test
+ * of the same box passes later (which still runs): skipping the others changes no result, only saves them a trip each.
+ * Scenes with fewer than 6 entities (the pass costs more than the trips it saves: three-entity teapot scene 6110 against
+ * 6925 Mpaths/s with it, twelve-entity box scene 8370 against 6915) or more than 31 (the mask is one word) go without. */
+static constexpr int kPrepassMinEntities = 6;
+__device__ __forceinline__ bool uses_entity_mask(const PtSceneDev &sc) { return sc.n_entities >= kPrepassMinEntities && sc.n_entities <= 31; }
+
 /* after an entity has been dealt with: on to the next one, or the ray is finished */
+template <bool PREPASS>
 __device__ __forceinline__ int next_entity_mode(const PtSceneDev &sc, const Lane &L) {
+    if (PREPASS && uses_entity_mask(sc)) return (L.emask >> L.ent) == 0u ? M_DONE : M_ENTITY;      /* ent <= 31 here */
     return L.ent >= sc.n_entities ? M_DONE : M_ENTITY;
 }
 
@@ -210,13 +222,18 @@ __device__ __forceinline__ void lane_start_ray(Lane &L, V3 o, V3 d) {
  * dgf:39-89: mirror the ray about the octree centre per negative direction component, root
  * interval, entry test).
  */
-template <bool STATS>
+template <bool STATS, bool PREPASS>
 __device__ __forceinline__ void entity_block(const PtSceneDev &sc, Lane &L, Stats &st) {
-    if (L.ent >= sc.n_entities) { L.mode = M_DONE; return; }
+    const bool masked = PREPASS && uses_entity_mask(sc);
+    if (masked) {
+        const uint32_t left = L.emask >> L.ent;
+        if (left == 0u) { L.mode = M_DONE; return; }
+        L.ent += __builtin_ctz(left);     /* entities in between are not worth a visit */
+    } else if (L.ent >= sc.n_entities) { L.mode = M_DONE; return; }
     const PtEntity &e = sc.entities[L.ent];
     const int32_t ei = L.ent;
     L.ent = ei + 1;                       /* default: move on to the next entity, or finish */
-    L.mode = next_entity_mode(sc, L);
+    L.mode = next_entity_mode<PREPASS>(sc, L);
     if (e.shape == PT_SHAPE_SPHERE) {     /* dgf:257-275; a sphere hit clears the triangle */
         const V3 dd = L.o - mk(e.center[0], e.center[1], e.center[2]);
         const float p1 = -dot3(L.d, dd);
@@ -231,7 +248,7 @@ __device__ __forceinline__ void entity_block(const PtSceneDev &sc, Lane &L, Stat
         }
         return;
     }
-    if (STATS) st.aabb_tests++;
+    if (STATS && !masked) st.aabb_tests++;        /* (the pre-pass has counted the box tests of all meshes) */
     const V3 fr = mk(clamp_frac(L.d.x), clamp_frac(L.d.y), clamp_frac(L.d.z));
     if (!slab_test(e.aabb_min, e.aabb_max, L.o, fr, L.best.t)) return;
     if (e.octree_depth == 0) {            /* dgf:286-291 */
@@ -268,6 +285,23 @@ __device__ __forceinline__ void entity_block(const PtSceneDev &sc, Lane &L, Stat
     L.mode = M_NODE;
 }
 
+template <bool STATS>
+__device__ __forceinline__ void entity_prepass(const PtSceneDev &sc, Lane &L, Stats &st) {
+    if (!uses_entity_mask(sc)) return;
+    const V3 fr = mk(clamp_frac(L.d.x), clamp_frac(L.d.y), clamp_frac(L.d.z));
+    uint32_t m = 0u;
+    for (int e = 0; e < sc.n_entities; e++) {          /* the same trip count in every lane */
+        const PtEntity &en = sc.entities[e];
+        bool visit = true;
+        if (en.shape != PT_SHAPE_SPHERE) {
+            if (STATS) st.aabb_tests++;
+            visit = slab_test(en.aabb_min, en.aabb_max, L.o, fr, FLT_MAX);
+        }
+        m |= visit ? (1u << e) : 0u;
+    }
+    L.emask = m;
+}
+
 /*
  * NODE block: proc_subtree's child loop (dgf:159-188) at the current inner node, one entered child
  * per trip.
@@ -293,12 +327,12 @@ __device__ __forceinline__ void entity_block(const PtSceneDev &sc, Lane &L, Stat
  * (A counting build keeps a frame while rejected members are left to count, and may find a frame without members
  * on return: it then returns again in its next trip.)
  */
-template <bool STATS>
+template <bool STATS, bool PREPASS>
 __device__ __forceinline__ void node_block(const PtSceneDev &sc, Lane &L, Stats &st, float4 *stack, uint32_t *stack1, int stride) {
     if ((L.todo & 0xFFu) == 0u) {
         if (STATS) st.node_visits += __popc((L.todo >> 8) & 0xFFu);
         const uint32_t above = L.framed >> L.rem;              /* bit 0: the parent's slot */
-        if (above == 0u) { L.mode = next_entity_mode(sc, L); return; }     /* walk finished without an accepted leaf */
+        if (above == 0u) { L.mode = next_entity_mode<PREPASS>(sc, L); return; }     /* walk finished without an accepted leaf */
         const int up = __builtin_ctz(above);
         const int slot = L.rem + up;
         const float4 s = stack[slot * stride];
@@ -416,7 +450,7 @@ __device__ __forceinline__ void node_block(const PtSceneDev &sc, Lane &L, Stats 
  */
 typedef float f2 __attribute__((ext_vector_type(2)));
 
-template <bool STATS, bool LOG>
+template <bool STATS, bool LOG, bool PREPASS>
 __device__ __forceinline__ void leaf_block(const PtSceneDev &sc, Lane &L, Stats &st, TriLog &lg) {
     const uint32_t idx = L.tri_cur;
     const bool two = L.tri_left != 1u;
@@ -483,7 +517,7 @@ __device__ __forceinline__ void leaf_block(const PtSceneDev &sc, Lane &L, Stats 
     L.best.t = bt; L.best.bu = bbu; L.best.bv = bbv; L.best.entity = bent; L.best.rec = brec;
     if (L.tri_left == 0u) {
         if (L.path != 0u && bent != L.ent - 1) L.mode = M_NODE;
-        else L.mode = next_entity_mode(sc, L);
+        else L.mode = next_entity_mode<PREPASS>(sc, L);
     }
 }
 
@@ -645,7 +679,7 @@ __device__ __forceinline__ void leaf_coop(const PtSceneDev &sc, Lane &L, Stats &
         L.tri_left = my_left - min(my_left, 2u * np);
         if (L.tri_left == 0u) {
             if (L.path != 0u && L.best.entity != L.ent - 1) L.mode = M_NODE;
-            else L.mode = next_entity_mode(sc, L);
+            else L.mode = next_entity_mode<false>(sc, L);
         }
     }
 }
@@ -655,10 +689,11 @@ __device__ __forceinline__ void leaf_coop(const PtSceneDev &sc, Lane &L, Stats &
  * until at least `done_quota` lanes wait in M_DONE (so the caller can shade / refill them together).
  * The block with the most waiting lanes runs next, for a few trips while it stays well filled.
  */
-template <bool STATS, bool LOG, bool COOP>
+template <bool STATS, bool LOG, bool COOP, bool PREPASS>
 __device__ __forceinline__ void trace_wave(const PtSceneDev &sc, Lane &L, Stats &st, TriLog &lg, float4 *stack, uint32_t *stack1,
                                            int stride, int done_quota, int leaf_quota, CoopLds *coop, int lane) {
     static_assert(!(LOG && COOP), "the cooperative leaf phase keeps no test log");
+    static_assert(!(PREPASS && COOP), "the entity pre-pass belongs to the builds for small scenes");
     for (;;) {
         const int n_ent = __popcll(__ballot(L.mode == M_ENTITY));
         const int n_node = __popcll(__ballot(L.mode == M_NODE));
@@ -675,14 +710,14 @@ __device__ __forceinline__ void trace_wave(const PtSceneDev &sc, Lane &L, Stats 
         const int which = (n_ent >= n_node && n_ent >= n_leaf) ? 0 : (!leaf_first ? 1 : 2);
         if (which == 0) {
             if (STATS) st.ent_trips++;
-            if (L.mode == M_ENTITY) { if (STATS) st.ent_lanes++; entity_block<STATS>(sc, L, st); }
+            if (L.mode == M_ENTITY) { if (STATS) st.ent_lanes++; entity_block<STATS, PREPASS>(sc, L, st); }
         }
         if (which == 1) {
             int trips = 0;
 #pragma nounroll
             do {
                 if (STATS) st.node_trips++;
-                if (L.mode == M_NODE) { if (STATS) st.node_lanes++; node_block<STATS>(sc, L, st, stack, stack1, stride); }
+                if (L.mode == M_NODE) { if (STATS) st.node_lanes++; node_block<STATS, PREPASS>(sc, L, st, stack, stack1, stride); }
             } while (++trips < PT_TRIPS && PT_KEEP_NODE * __popcll(__ballot(L.mode == M_NODE)) >= n_node &&
                      !(COOP && __popcll(__ballot(L.mode == M_LEAF)) >= leaf_quota));
         }
@@ -694,7 +729,7 @@ __device__ __forceinline__ void trace_wave(const PtSceneDev &sc, Lane &L, Stats 
 #pragma nounroll
                 do {
                     if (STATS) st.leaf_trips++;
-                    if (L.mode == M_LEAF) { if (STATS) st.leaf_lanes++; leaf_block<STATS, LOG>(sc, L, st, lg); }
+                    if (L.mode == M_LEAF) { if (STATS) st.leaf_lanes++; leaf_block<STATS, LOG, PREPASS>(sc, L, st, lg); }
                 } while (++trips < PT_TRIPS && PT_KEEP_LEAF * __popcll(__ballot(L.mode == M_LEAF)) >= n_leaf);
             }
         }

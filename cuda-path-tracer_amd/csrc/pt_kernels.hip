@@ -310,6 +310,7 @@ __global__ void __launch_bounds__(kBlock) trace_kernel(PtSceneDev sc, const floa
                 st.segments++;
                 lane_start_ray(L, mk(rays[6 * i], rays[6 * i + 1], rays[6 * i + 2]),
                                mk(rays[6 * i + 3], rays[6 * i + 4], rays[6 * i + 5]));
+                if (LOG) entity_prepass<true>(sc, L, st);          /* (the logging build is the one without the cooperative phase) */
                 if (LOG) { lg.p = log + i * log_stride; lg.p[0] = 0; }
             } else {
                 L.mode = M_IDLE;
@@ -317,7 +318,7 @@ __global__ void __launch_bounds__(kBlock) trace_kernel(PtSceneDev sc, const floa
         }
         first = false;
         if (__ballot(L.mode != M_IDLE) == 0ull) break;
-        trace_wave<true, LOG, !LOG>(sc, L, st, lg, stack, stack1, kBlock, kDoneQuota, kLeafQuota, coop, threadIdx.x & 63);
+        trace_wave<true, LOG, !LOG, LOG>(sc, L, st, lg, stack, stack1, kBlock, kDoneQuota, kLeafQuota, coop, threadIdx.x & 63);
     }
     if (stats) {
         flush_stat(&stats[0], st.segments);
@@ -392,7 +393,7 @@ __device__ __forceinline__ uint32_t udiv(uint32_t n, const UDiv &d) {
     return (t + ((n - t) >> d.sh1)) >> d.sh2;
 }
 
-template <bool STATS, int WAVES, bool COOP>
+template <bool STATS, int WAVES, bool COOP, bool PREPASS>
 __global__ void __launch_bounds__(kBlock, WAVES) render_kernel(RenderParams P) {
     extern __shared__ float4 lds_stack[];
     float4 *stack = lds_stack + threadIdx.x;
@@ -549,6 +550,7 @@ __global__ void __launch_bounds__(kBlock, WAVES) render_kernel(RenderParams P) {
                 } else {
                     if (STATS) st.segments++;
                     lane_start_ray(L, o, d);
+                    if (PREPASS) entity_prepass<STATS>(P.sc, L, st);
                 }
             } else {
                 V3 o, d;
@@ -558,13 +560,14 @@ __global__ void __launch_bounds__(kBlock, WAVES) render_kernel(RenderParams P) {
                 meta &= ~kBounceMask;
                 if (STATS) { st.paths++; st.segments++; }
                 lane_start_ray(L, o, d);
+                if (PREPASS) entity_prepass<STATS>(P.sc, L, st);
             }
         }
         if (__ballot(L.mode != M_IDLE) == 0ull) {
             if (__ballot(!(meta & kDoneBit)) == 0ull) break;      /* every lane is out of work: the grid drains */
             continue;                                /* e.g. lanes that drew an out-of-image slot ask again */
         }
-        trace_wave<STATS, false, COOP>(P.sc, L, st, lg, stack, stack1, kBlock, P.done_quota, P.leaf_quota, coop, lane);
+        trace_wave<STATS, false, COOP, PREPASS>(P.sc, L, st, lg, stack, stack1, kBlock, P.done_quota, P.leaf_quota, coop, lane);
     }
     if (STATS && P.stats) {
         flush_stat(&P.stats[0], st.segments);
@@ -694,15 +697,21 @@ int launch_render(RenderParams p, int n_cu, int max_queues, bool heavy, hipStrea
         /* deep octrees need so much LDS for their stacks that fewer workgroups fit: the build for 3 waves per SIMD
          * then has the larger register budget for the same residency */
         if (per_cu >= kWavesHeavy) {
-            if (p.stats) hipLaunchKernelGGL((render_kernel<true, kWavesHeavy, true>), grid, block, lds, stream, p);
-            else hipLaunchKernelGGL((render_kernel<false, kWavesHeavy, true>), grid, block, lds, stream, p);
+            if (p.stats) hipLaunchKernelGGL((render_kernel<true, kWavesHeavy, true, false>), grid, block, lds, stream, p);
+            else hipLaunchKernelGGL((render_kernel<false, kWavesHeavy, true, false>), grid, block, lds, stream, p);
         } else {
-            if (p.stats) hipLaunchKernelGGL((render_kernel<true, 3, true>), grid, block, lds, stream, p);
-            else hipLaunchKernelGGL((render_kernel<false, 3, true>), grid, block, lds, stream, p);
+            if (p.stats) hipLaunchKernelGGL((render_kernel<true, 3, true, false>), grid, block, lds, stream, p);
+            else hipLaunchKernelGGL((render_kernel<false, 3, true, false>), grid, block, lds, stream, p);
         }
     } else {
-        if (p.stats) hipLaunchKernelGGL((render_kernel<true, kWavesLight, false>), grid, block, lds, stream, p);
-        else hipLaunchKernelGGL((render_kernel<false, kWavesLight, false>), grid, block, lds, stream, p);
+        /* scenes of many small entities get the instantiation with the entity pre-pass */
+        if (p.sc.n_entities >= kPrepassMinEntities && p.sc.n_entities <= 31) {
+            if (p.stats) hipLaunchKernelGGL((render_kernel<true, kWavesLight, false, true>), grid, block, lds, stream, p);
+            else hipLaunchKernelGGL((render_kernel<false, kWavesLight, false, true>), grid, block, lds, stream, p);
+        } else {
+            if (p.stats) hipLaunchKernelGGL((render_kernel<true, kWavesLight, false, false>), grid, block, lds, stream, p);
+            else hipLaunchKernelGGL((render_kernel<false, kWavesLight, false, false>), grid, block, lds, stream, p);
+        }
     }
     PT_HIP(hipGetLastError());
     return 0;
