@@ -183,6 +183,9 @@ def test_render_edge_cases(pt, scenes):
         g.render_accumulate(cam, 1, 0, 4, 0, split.ptr)
     with pytest.raises(pt.PtError, match="sample range"):
         g.render_accumulate(cam, 1, 4, 2, 4, split.ptr)
+    # a lane counts the samples of its slice down in 16 bits: more than 64 slices x 65535 samples is refused, not wrapped
+    with pytest.raises(pt.PtError, match="65535 samples per slice"):
+        g.render_accumulate(cam, 1, 0, 64 * 65535 + 64, 4, split.ptr)
     # resolution not divisible by the 8x8 work tile: every pixel is still rendered
     desc = scenes.cornellbox_scene(res=(37, 21))
     g2, cam2 = pt.scene_from_description(desc)
