@@ -69,11 +69,8 @@ __device__ __forceinline__ float luminosity(V3 c) {
 /* Traffic probes (profiles/fetch_attr.sh): builds that read texel 0 of every texture (PT_PROBE_TEXEL0) or of the
  * environment map (PT_PROBE_HDRI0) instead of the addressed one -- same instructions, same paths through the scene up to
  * the colours, but the array stays in cache: the drop in memory-side fetch bytes is that array's share.  Not renders. */
-__device__ __forceinline__ int to_index(float f, int n) {   /* C truncation, clamped into the image */
-    if (!(f >= 0.0f)) return 0;
-    if (f >= (float)n) return n - 1;
-    int i = (int)f;
-    return i > n - 1 ? n - 1 : i;
+__device__ __forceinline__ int to_index(float f, int n) {   /* C truncation, clamped into the image (NaN -> 0) */
+    return (int)__builtin_amdgcn_fmed3f(f, 0.0f, (float)(n - 1));      /* n < 2^24: n - 1 is exact; one clamp, no branches */
 }
 
 /* src/texture.cuh:22-43 (indices clamped into the texture) */
