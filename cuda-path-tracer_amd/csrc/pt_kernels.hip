@@ -118,7 +118,8 @@ __device__ __forceinline__ V3 sample_hdri(const PtSceneDev &sc, V3 v, Stats &st)
         res = mk(p[0], p[1], p[2]);
     } else {
         const int x_l = to_index(x_c * (float)W, W), y_l = to_index(y_c * (float)H, H);
-        const int x_r = (x_l + 1) % W, y_r = (y_l + 1) % H;
+        /* (x_l + 1) % W with x_l in [0, W): a wrap, not a division */
+        const int x_r = x_l + 1 == W ? 0 : x_l + 1, y_r = y_l + 1 == H ? 0 : y_l + 1;
         const float xw = fminf(fmaxf(x_c * (float)W - (float)x_l, 0.0f), 1.0f);
         const float yw = fminf(fmaxf(y_c * (float)H - (float)y_l, 0.0f), 1.0f);
         const float *ul = cols + 3 * ((size_t)y_l * W + x_l), *ur = cols + 3 * ((size_t)y_l * W + x_r);
@@ -162,7 +163,7 @@ __device__ __forceinline__ V3 to_world(V3 v, const Basis &B) {
 __device__ __forceinline__ V3 sample_hemisphere(V3 dir, float alpha, float xi_c, float xi_p) {
     PT_SHADING_FP
     const float cos_theta = fast_pow(xi_c, fast_rcp(alpha + 1.0f));
-    const float sin_theta = __builtin_sqrtf(fmaxf(1.0f - cos_theta * cos_theta, 0.0f));
+    const float sin_theta = __builtin_amdgcn_sqrtf(fmaxf(1.0f - cos_theta * cos_theta, 0.0f));      /* v_sqrt_f32: 1 ulp */
     const V3 ts = mk(cos_rev(xi_p) * sin_theta, sin_rev(xi_p) * sin_theta, cos_theta);
     return to_world(ts, tangent_space(dir));
 }
