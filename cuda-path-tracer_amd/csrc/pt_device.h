@@ -632,12 +632,17 @@ __device__ __forceinline__ void leaf_coop(const PtSceneDev &sc, Lane &L, Stats &
             const f2 uv = ua + va;
             const float far = bt0 * 1.00001f;
             uint32_t pend = 0;
-            if (!(fabsf(det.x) < 0.000000001f) &&
-                !((ua.x < -0.00011f) || (ua.x > 1.00011f) || (va.x < -0.00011f) || (uv.x > 1.00012f) || (ta.x < -1e-30f) || (ta.x > far)))
-                pend = 1u;
-            if (two && !(fabsf(det.y) < 0.000000001f) &&
-                !((ua.y < -0.00011f) || (ua.y > 1.00011f) || (va.y < -0.00011f) || (uv.y > 1.00012f) || (ta.y < -1e-30f) || (ta.y > far)))
-                pend |= 2u;
+            {
+                /* the six bounds as margins (the sign of a rounded sum or difference is the sign of the exact one), the
+                 * smallest margin decides: packed adds serve both tests */
+                const f2 m1 = ua + 0.00011f, m2 = 1.00011f - ua, m3 = va + 0.00011f, m4 = 1.00012f - uv, m5 = ta + 1e-30f;
+                const f2 farv = {far, far};
+                const f2 m6 = farv - ta;
+                const float wx = fminf(fminf(fminf(m1.x, m2.x), m3.x), fminf(fminf(m4.x, m5.x), m6.x));
+                const float wy = fminf(fminf(fminf(m1.y, m2.y), m3.y), fminf(fminf(m4.y, m5.y), m6.y));
+                if (!(fabsf(det.x) < 0.000000001f) && !(wx < 0.0f)) pend = 1u;
+                if (two && !(fabsf(det.y) < 0.000000001f) && !(wy < 0.0f)) pend |= 2u;
+            }
             float bt = bt0, bu = 0.f, bv = 0.f;
             uint32_t slot = 0;
             bool has = false;
