@@ -569,14 +569,18 @@ __device__ __forceinline__ void leaf_coop(const PtSceneDev &sc, Lane &L, Stats &
     const uint32_t my_left = mine ? L.tri_left : 0u;
     const uint32_t my_pairs = (my_left + 1u) >> 1;
     const uint32_t np = min(my_pairs, kCoopMaxPairs);
-    /* exclusive prefix and total of np over the wave, bit plane by bit plane */
-    uint32_t excl = 0, T = 0;
-#pragma unroll
-    for (int b = 0; b < kCoopPlanes; b++) {
-        const unsigned long long m = __ballot(((np >> b) & 1u) != 0u);
-        excl += lanes_below(m) << b;
-        T += (uint32_t)__popcll(m) << b;
-    }
+    /* exclusive prefix and total of np over the wave: a scan on the cross-lane data path, log steps inside each row of
+     * 16 lanes (a lane without a source adds zero), then the last lane of a row broadcast into the rows after it.
+     * All 64 lanes are active here. */
+    uint32_t incl = np;
+    incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x111, 0xf, 0xf, true);      /* row_shr:1 */
+    incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x112, 0xf, 0xf, true);      /* row_shr:2 */
+    incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x114, 0xf, 0xf, true);      /* row_shr:4 */
+    incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x118, 0xf, 0xf, true);      /* row_shr:8 */
+    incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x142, 0xa, 0xf, false);     /* row_bcast:15 into rows 1, 3 */
+    incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x143, 0xc, 0xf, false);     /* row_bcast:31 into rows 2, 3 */
+    const uint32_t excl = incl - np;
+    const uint32_t T = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
     const unsigned long long runs = __ballot(np != 0u);
     if (lane < (int)kCoopMaxPairs) C->starts[lane] = 0ull;
     C->res[lane] = ~0ull;
