@@ -150,7 +150,7 @@ __device__ __forceinline__ uint32_t child_list(float t0x, float t0y, float t0z, 
      * (t1 once the bit is set, tM before), so that a step is three comparisons and three selects; the flag logic is
      * mask arithmetic on the scalar unit */
     const float te = fmaxf(fmaxf(t0x, t0y), t0z);
-    bool bx = tMx < te, by = tMy < te, bz = tMz < te;
+    const bool bx = tMx < te, by = tMy < te, bz = tMz < te;
     float ex = bx ? t1x : tMx, ey = by ? t1y : tMy, ez = bz ? t1z : tMz;
     uint32_t c = (bx ? 4u : 0u) | (by ? 2u : 0u) | (bz ? 1u : 0u);
     uint32_t list = nm << 24;
@@ -170,10 +170,12 @@ __device__ __forceinline__ uint32_t child_list(float t0x, float t0y, float t0z, 
              * with ez <= ex and ez <= ey: written so that the three flags are plain mask arithmetic */
             const bool sx = s1 && s2, sy = !s1 && s3;
             const bool sz = !s2 && !s3;
-            open = open && !((sx && bx) || (sy && by) || (sz && bz));          /* the bit is set already: the node is left */
-            bx = bx || sx; by = by || sy; bz = bz || sz;
+            /* the node is left when the winning axis' bit is set already, i.e. when the child number does not change: one
+             * integer compare instead of carrying the three bits as lane masks (scalar instructions are not free) */
+            const uint32_t cn = c | (sx ? 4u : (sy ? 2u : 1u));
+            open = open && (cn != c);
+            c = cn;
             ex = sx ? t1x : ex; ey = sy ? t1y : ey; ez = sz ? t1z : ez;
-            c |= sx ? 4u : (sy ? 2u : 1u);
         }
     }
     return list;
