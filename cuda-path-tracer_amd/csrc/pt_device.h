@@ -135,7 +135,7 @@ struct Lane {
  *   bits  8..15  rej: child c is a member and exists but fails that test (entered and left at once: it
  *                only counts; kept in counting builds)
  *   bits 24..31  the node's child mask
- * Members after the one that leaves the node have neither flag.
+ * Steps after the one that leaves the node repeat the last member.
  */
 template <bool STATS>
 __device__ __forceinline__ uint32_t child_list(float t0x, float t0y, float t0z, float t1x, float t1y, float t1z, uint32_t nm,
@@ -153,31 +153,39 @@ __device__ __forceinline__ uint32_t child_list(float t0x, float t0y, float t0z, 
     const bool bx = tMx < te, by = tMy < te, bz = tMz < te;
     float ex = bx ? t1x : tMx, ey = by ? t1y : tMy, ez = bz ? t1z : tMz;
     uint32_t c = (bx ? 4u : 0u) | (by ? 2u : 0u) | (bz ? 1u : 0u);
-    uint32_t list = nm << 24;
-    bool open = true;
+    /* dgf:142, (ex < 0 || ey < 0 || ey < 0): y twice, never z.  The parameters are products of finite differences and
+     * clamped reciprocals, never NaN, so "negative" is "bit pattern above -0.0".  A member's ex is the node's t1x when
+     * its x bit is set, and the node would not have been entered with a negative t1x (the same test, one level up, or
+     * the root's): only tMx can fail, for the four children without the x bit; likewise y */
+    const uint32_t rej = (__float_as_uint(tMx) > 0x80000000u ? 0x0Fu : 0u) | (__float_as_uint(tMy) > 0x80000000u ? 0x33u : 0u);
+    uint32_t cs[4];
+    cs[0] = c;
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
+    for (int i = 0; i < 3; i++) {
         /* member i = child c, whose exit parameters are (ex, ey, ez) */
-        const uint32_t present = __builtin_amdgcn_ubfe(nm, c ^ (uint32_t)a, 1u);
-        /* dgf:142, (ex < 0 || ey < 0 || ey < 0): y twice, never z.  The parameters are products of finite
-         * differences and clamped reciprocals, never NaN, so "negative" is "bit pattern above -0.0" */
-        const bool rejected = max(__float_as_uint(ex), __float_as_uint(ey)) > 0x80000000u;
-        list |= ((open && !rejected) ? present : 0u) << c;
-        if (STATS) list |= ((open && rejected) ? present : 0u) << (c + 8u);
-        if (i < 3) {
-            const bool s1 = ex < ey, s2 = ex < ez, s3 = ey < ez;              /* next_node, dgf:116-126 */
-            /* x wins with ex < ey and ex < ez, y with ey <= ex and ey < ez, z otherwise, i.e. (no NaNs)
-             * with ez <= ex and ez <= ey: written so that the three flags are plain mask arithmetic */
-            const bool sx = s1 && s2, sy = !s1 && s3;
-            const bool sz = !s2 && !s3;
-            /* the node is left when the winning axis' bit is set already, i.e. when the child number does not change: one
-             * integer compare instead of carrying the three bits as lane masks (scalar instructions are not free) */
-            const uint32_t cn = c | (sx ? 4u : (sy ? 2u : 1u));
-            open = open && (cn != c);
-            c = cn;
-            ex = sx ? t1x : ex; ey = sy ? t1y : ey; ez = sz ? t1z : ez;
-        }
+        const bool s1 = ex < ey, s2 = ex < ez, s3 = ey < ez;              /* next_node, dgf:116-126 */
+        /* x wins with ex < ey and ex < ez, y with ey <= ex and ey < ez, z otherwise, i.e. (no NaNs)
+         * with ez <= ex and ez <= ey: written so that the three flags are plain mask arithmetic */
+        const bool sx = s1 && s2, sy = !s1 && s3;
+        const bool sz = !s2 && !s3;
+        /* the node is left when the winning axis' bit is set already.  No flag is kept for that: the exit parameters
+         * do not change in such a step, so every later step picks the same axis again and the remaining members
+         * repeat the last real one -- setting its bit in the set again changes nothing */
+        c |= sx ? 4u : (sy ? 2u : 1u);
+        cs[i + 1] = c;
+        ex = sx ? t1x : ex; ey = sy ? t1y : ey; ez = sz ? t1z : ez;
     }
+    /* Everything above works on the interval alone.  The node's record, fetched at the start of the trip, is first
+     * needed here; the fence and the empty statement after it (which pins the record and the last step's result to
+     * this point) keep the compiler from pulling uses of the record, and with them the wait for the fetch, up into
+     * the steps: +1.5 % on the whole kernel */
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("" : "+v"(nm), "+v"(cs[3]));
+    uint32_t members = 0u;
+#pragma unroll
+    for (int i = 0; i < 4; i++) members |= __builtin_amdgcn_ubfe(nm, cs[i] ^ (uint32_t)a, 1u) << cs[i];
+    uint32_t list = (nm << 24) | (members & ~rej);
+    if (STATS) list |= (members & rej) << 8;
     return list;
 }
 
@@ -427,8 +435,8 @@ __device__ __forceinline__ void node_block(const PtSceneDev &sc, Lane &L, Stats 
     stack[L.rem * stride] = s;
     stack1[L.rem * stride] = L.todo;
     L.path = last ? L.path : ((L.path << 3) | (uint32_t)curr);
-    asm("v_mov_b32_e32 %0, %1" : "+v"(L.nb) : "v"(rec.a));
     L.todo = child_list<STATS>(L.t0x, L.t0y, L.t0z, L.t1x, L.t1y, L.t1z, rec.b, L.a);
+    asm volatile("v_mov_b32_e32 %0, %1" : "+v"(L.nb) : "v"(rec.a));     /* after the list: the record is used as late as possible */
 }
 
 /*
