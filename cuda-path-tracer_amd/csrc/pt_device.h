@@ -150,9 +150,21 @@ __device__ __forceinline__ uint32_t child_list(float t0x, float t0y, float t0z, 
      * (t1 once the bit is set, tM before), so that a step is three comparisons and three selects; the flag logic is
      * mask arithmetic on the scalar unit */
     const float te = fmaxf(fmaxf(t0x, t0y), t0z);
-    const bool bx = tMx < te, by = tMy < te, bz = tMz < te;
-    float ex = bx ? t1x : tMx, ey = by ? t1y : tMy, ez = bz ? t1z : tMz;
-    uint32_t c = (bx ? 4u : 0u) | (by ? 2u : 0u) | (bz ? 1u : 0u);
+    /* per axis: bit = tM < te, shifted into the child number through the carry (c = 2 c + bit); exit = bit ? t1 : tM */
+    float ex, ey, ez;
+    uint32_t c = 0u;
+    asm("v_cmp_lt_f32_e32 vcc, %[tMx], %[te]\n\t"
+        "v_cndmask_b32_e32 %[ex], %[tMx], %[t1x], vcc\n\t"
+        "v_addc_co_u32_e32 %[c], vcc, %[c], %[c], vcc\n\t"
+        "v_cmp_lt_f32_e32 vcc, %[tMy], %[te]\n\t"
+        "v_cndmask_b32_e32 %[ey], %[tMy], %[t1y], vcc\n\t"
+        "v_addc_co_u32_e32 %[c], vcc, %[c], %[c], vcc\n\t"
+        "v_cmp_lt_f32_e32 vcc, %[tMz], %[te]\n\t"
+        "v_cndmask_b32_e32 %[ez], %[tMz], %[t1z], vcc\n\t"
+        "v_addc_co_u32_e32 %[c], vcc, %[c], %[c], vcc"
+        : [ex] "=&v"(ex), [ey] "=&v"(ey), [ez] "=&v"(ez), [c] "+v"(c)
+        : [tMx] "v"(tMx), [tMy] "v"(tMy), [tMz] "v"(tMz), [te] "v"(te), [t1x] "v"(t1x), [t1y] "v"(t1y), [t1z] "v"(t1z)
+        : "vcc");
     /* dgf:142, (ex < 0 || ey < 0 || ey < 0): y twice, never z.  The parameters are products of finite differences and
      * clamped reciprocals, never NaN, so "negative" is "bit pattern above -0.0".  A member's ex is the node's t1x when
      * its x bit is set, and the node would not have been entered with a negative t1x (the same test, one level up, or
@@ -401,15 +413,19 @@ __device__ __forceinline__ void node_block(const PtSceneDev &sc, Lane &L, Stats 
         }
         return;
     }
-    const bool last = (L.todo & 0xFFFFu) == 0u;              /* nothing left at this node: no frame */
+    /* nothing left at this node: no frame.  As a 0 / ~0 word, so that the three updates that depend on it are one
+     * bitwise select each instead of a compare and selects on its mask */
+    uint32_t last;                                           /* = (int32_t)((L.todo & 0xFFFF) - 1) >> 31, kept from being turned back into a compare */
+    asm("v_add_u32_e32 %0, -1, %1\n\tv_ashrrev_i32_e32 %0, 31, %0" : "=v"(last) : "v"(L.todo & 0xFFFFu));
     /* which bound of each axis goes into the slot: frame -> the one the child does not inherit (t0 where it takes
      * the upper half); no frame -> the one this node inherited from its parent (t1 where IT is an upper half: the last
      * digit of `path`, which is the parent's if the parent has a frame; otherwise nobody reads the slot) */
-    const uint32_t pick = last ? (L.path & 7u) : ~(uint32_t)curr;
+    uint32_t pick;                                           /* last ? path : ~curr; bits 0..2 are read */
+    asm("v_bitop3_b32 %0, %1, %2, %3 bitop3:0xc5" : "=v"(pick) : "v"(last), "v"(L.path), "v"(curr));
     float4 s;
     asm("v_add_u32_e32 %0, -1, %0" : "+v"(L.rem));               /* in place, like the interval below */
     const uint32_t bit = 1u << L.rem;
-    L.framed = last ? (L.framed & ~bit) : (L.framed | bit);
+    L.framed = (L.framed & ~bit) | (bit & ~last);
     /* the child's interval, selected in place (left to the compiler it lands in fresh registers and is copied back and
      * forth to join the lanes that do not descend); the slot words first: they read the bounds the others overwrite */
     asm("v_bfe_i32 %[sx], %[pick], 2, 1\n\t"
@@ -434,7 +450,7 @@ __device__ __forceinline__ void node_block(const PtSceneDev &sc, Lane &L, Stats 
     s.w = __uint_as_float(L.nb);
     stack[L.rem * stride] = s;
     stack1[L.rem * stride] = L.todo;
-    L.path = last ? L.path : ((L.path << 3) | (uint32_t)curr);
+    asm("v_bitop3_b32 %0, %1, %0, %2 bitop3:0xca" : "+v"(L.path) : "v"(last), "v"((L.path << 3) | (uint32_t)curr));   /* last ? path : path.curr */
     L.todo = child_list<STATS>(L.t0x, L.t0y, L.t0z, L.t1x, L.t1y, L.t1z, rec.b, L.a);
     asm volatile("v_mov_b32_e32 %0, %1" : "+v"(L.nb) : "v"(rec.a));     /* after the list: the record is used as late as possible */
 }
