@@ -735,6 +735,12 @@ __device__ __forceinline__ int count_lanes(bool p) {
     return n;
 }
 
+/* Node trips between two looks at the lane counts that end the node block: the counts cost two vector compares and
+ * eight scalar instructions, 4 % of a trip.  Measured on the north-star scene: 2 -> +1.6 %, 3 and 4 -> +1.3 % and 0 %
+ * (the block then runs on with too few lanes); no gain for the leaf trips of the builds without the cooperative phase */
+#ifndef PT_NODE_GROUP
+#define PT_NODE_GROUP 2
+#endif
 template <bool STATS, bool LOG, bool COOP, bool PREPASS>
 __device__ __forceinline__ void trace_wave(const PtSceneDev &sc, Lane &L, Stats &st, TriLog &lg, float4 *stack, uint32_t *stack1,
                                            int stride, int done_quota, int leaf_quota, CoopLds *coop, int lane) {
@@ -762,9 +768,12 @@ __device__ __forceinline__ void trace_wave(const PtSceneDev &sc, Lane &L, Stats 
             int trips = 0;
 #pragma nounroll
             do {
-                if (STATS) st.node_trips++;
-                if (L.mode == M_NODE) { if (STATS) st.node_lanes++; node_block<STATS, PREPASS>(sc, L, st, stack, stack1, stride); }
-            } while (++trips < PT_TRIPS && PT_KEEP_NODE * __popcll(__ballot(L.mode == M_NODE)) >= n_node &&
+#pragma unroll
+                for (int u = 0; u < PT_NODE_GROUP; u++) {
+                    if (STATS) st.node_trips++;
+                    if (L.mode == M_NODE) { if (STATS) st.node_lanes++; node_block<STATS, PREPASS>(sc, L, st, stack, stack1, stride); }
+                }
+            } while ((trips += PT_NODE_GROUP) < PT_TRIPS && PT_KEEP_NODE * __popcll(__ballot(L.mode == M_NODE)) >= n_node &&
                      !(COOP && __popcll(__ballot(L.mode == M_LEAF)) >= leaf_quota));
         }
         if (which == 2) {
