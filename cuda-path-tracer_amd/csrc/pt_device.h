@@ -608,8 +608,12 @@ __device__ __forceinline__ void leaf_coop(const PtSceneDev &sc, Lane &L, Stats &
     const uint32_t excl = incl - np;
     const uint32_t T = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
     const unsigned long long runs = __ballot(np != 0u);
-    if (lane < (int)kCoopMaxPairs) C->starts[lane] = 0ull;
-    C->res[lane] = ~0ull;
+    /* the two constants are made here: left to the compiler they are hoisted out of the kernel's work loop, where one
+     * sat in a register pair for good and the other was spilled and came back from scratch memory in every phase */
+    unsigned long long zeros, ones;
+    asm volatile("v_mov_b64_e32 %0, 0\n\tv_mov_b64_e32 %1, -1" : "=v"(zeros), "=v"(ones));
+    if (lane < (int)kCoopMaxPairs) C->starts[lane] = zeros;
+    C->res[lane] = ones;
     wave_lds_fence();
     if (np != 0u) {
         atomicOr(&C->starts[excl >> 6], 1ull << (excl & 63u));
