@@ -703,23 +703,24 @@ __device__ __forceinline__ void leaf_coop(const PtSceneDev &sc, Lane &L, Stats &
         }
         wave_lds_fence();
     }
-    if (np != 0u) {
+    /* Results back into the lanes, as selects that every lane executes (no divergent region, so the lane state is
+     * updated in place): only an owner's slot can hold a key, and a lane without pairs in the phase has np = 0 */
+    {
         const unsigned long long key = C->res[lane];
-        if (key != ~0ull) {
-            const uint32_t oi = (uint32_t)key;
-            const uint32_t off = my_cur + (oi >> 1) * (uint32_t)sizeof(PtTriPair);
-            L.best.t = __uint_as_float((uint32_t)(key >> 32));
-            L.best.bu = C->win[lane][0];
-            L.best.bv = C->win[lane][1];
-            L.best.entity = L.ent - 1;
-            L.best.rec = (off >> 3) | (oi & 1u);
-        }
-        L.tri_cur = my_cur + np * (uint32_t)sizeof(PtTriPair);
-        L.tri_left = my_left - min(my_left, 2u * np);
-        if (L.tri_left == 0u) {
-            if (L.path != 0u && L.best.entity != L.ent - 1) L.mode = M_NODE;
-            else L.mode = next_entity_mode<false>(sc, L);
-        }
+        const bool got = key != ~0ull;
+        const uint32_t oi = (uint32_t)key;
+        const uint32_t off = my_cur + (oi >> 1) * (uint32_t)sizeof(PtTriPair);
+        const float wu = C->win[lane][0], wv = C->win[lane][1];
+        L.best.t = got ? __uint_as_float((uint32_t)(key >> 32)) : L.best.t;
+        L.best.bu = got ? wu : L.best.bu;
+        L.best.bv = got ? wv : L.best.bv;
+        L.best.entity = got ? L.ent - 1 : L.best.entity;
+        L.best.rec = got ? ((off >> 3) | (oi & 1u)) : L.best.rec;
+        L.tri_cur += np * (uint32_t)sizeof(PtTriPair);
+        L.tri_left -= min(my_left, 2u * np);
+        const bool finished = np != 0u && L.tri_left == 0u;
+        const int after = (L.path != 0u && L.best.entity != L.ent - 1) ? M_NODE : next_entity_mode<false>(sc, L);
+        L.mode = finished ? after : L.mode;
     }
 }
 
