@@ -421,6 +421,8 @@ int pt_scene_commit(pt_scene *scene) {
                     else nd.a = append_run(recs, h.positions.data(), h.tri.data(), T.leaf_tris.data() + nd.a, 0, (int64_t)nd.b);
                     nodes.push_back(nd);
                 }
+                e.root_a = nodes[node_base].a;
+                e.root_b = nodes[node_base].b;
                 if (h.octree_depth > max_depth) max_depth = h.octree_depth;
             }
         }

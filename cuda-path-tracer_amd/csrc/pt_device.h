@@ -244,22 +244,16 @@ __device__ __forceinline__ void lane_start_ray(Lane &L, V3 o, V3 d) {
  * dgf:39-89: mirror the ray about the octree centre per negative direction component, root
  * interval, entry test).
  */
-template <bool STATS, bool PREPASS>
-__device__ __forceinline__ void entity_block(const PtSceneDev &sc, Lane &L, Stats &st) {
-    const bool masked = PREPASS && uses_entity_mask(sc);
-    if (masked) {
-        const uint32_t left = L.emask >> L.ent;
-        if (left == 0u) { L.mode = M_DONE; return; }
-        L.ent += __builtin_ctz(left);     /* entities in between are not worth a visit */
-    } else if (L.ent >= sc.n_entities) { L.mode = M_DONE; return; }
-    const PtEntity &e = sc.entities[L.ent];
+/* (the block proper, on a view E of the entity's record: the record itself, or a copy of its rows in registers) */
+template <bool STATS, bool PREPASS, typename E>
+__device__ __forceinline__ void entity_visit(const PtSceneDev &sc, Lane &L, Stats &st, const E &e, const PtEntity *ep, bool masked) {
     const int32_t ei = L.ent;
     L.ent = ei + 1;                       /* default: move on to the next entity, or finish */
     L.mode = next_entity_mode<PREPASS>(sc, L);
     if (e.shape == PT_SHAPE_SPHERE) {     /* dgf:257-275; a sphere hit clears the triangle */
-        const V3 dd = L.o - mk(e.center[0], e.center[1], e.center[2]);
+        const V3 dd = L.o - mk(ep->center[0], ep->center[1], ep->center[2]);
         const float p1 = -dot3(L.d, dd);
-        const float p2sqr = ((p1 * p1) - dot3(dd, dd)) + (e.radius * e.radius);
+        const float p2sqr = ((p1 * p1) - dot3(dd, dd)) + (ep->radius * ep->radius);
         if (!(p2sqr < 0)) {
             const float p2 = 1.0f / rsqrt_ieee(p2sqr);
             const float t = p1 - p2 > 0 ? p1 - p2 : p1 + p2;
@@ -299,12 +293,45 @@ __device__ __forceinline__ void entity_block(const PtSceneDev &sc, Lane &L, Stat
     if (!((tmin < tmax) && (tmax > 0.0f))) return;
     if (STATS) st.node_visits++;          /* the root is entered */
     if ((t1x < 0.0f) || (t1y < 0.0f) || (t1y < 0.0f)) return;   /* dgf:142 (tests y twice, never z) */
-    const PtNode rec = sc.nodes[e.root_node];
     L.t0x = t0x; L.t0y = t0y; L.t0z = t0z; L.t1x = t1x; L.t1y = t1y; L.t1z = t1z;
-    L.nb = rec.a;
+    L.nb = e.root_a;                      /* the root's node record, copied into the entity's */
     L.a = a; L.path = 1u; L.framed = 0u; L.rem = e.octree_depth - 1;
-    L.todo = child_list<STATS>(t0x, t0y, t0z, t1x, t1y, t1z, rec.b, a);
+    L.todo = child_list<STATS>(t0x, t0y, t0z, t1x, t1y, t1z, e.root_b, a);
     L.mode = M_NODE;
+}
+
+template <bool STATS, bool PREPASS, bool TOGETHER>
+__device__ __forceinline__ void entity_block(const PtSceneDev &sc, Lane &L, Stats &st) {
+    const bool masked = PREPASS && uses_entity_mask(sc);
+    if (masked) {
+        const uint32_t left = L.emask >> L.ent;
+        if (left == 0u) { L.mode = M_DONE; return; }
+        L.ent += __builtin_ctz(left);     /* entities in between are not worth a visit */
+    } else if (L.ent >= sc.n_entities) { L.mode = M_DONE; return; }
+    /* TOGETHER: the rows of the record that a mesh needs are fetched at once, before anything is decided on them.  Read
+     * field by field where it is used, every decision (shape, box, octree depth, root region) waits for a fetch of its
+     * own, four in a row.  Pays for scenes of one large mesh (+2 % with 871 k triangles); scenes of many small meshes lose by
+     * it (box scene -6 %: most trips end at the box test).  (A sphere's centre and radius are fetched in its branch.) */
+    const PtEntity *ep = &sc.entities[L.ent];
+    if (!TOGETHER) { entity_visit<STATS, PREPASS>(sc, L, st, *ep, ep, masked); return; }
+    struct { int32_t shape, material, octree_depth; uint32_t root_node; float aabb_min[3]; uint32_t tri_first; float aabb_max[3]; uint32_t n_tris;
+             float region_min[3]; uint32_t shade_base; float region_max[3]; int32_t has_uvs; uint32_t root_a, root_b; } e;
+    {
+        typedef int iv4 __attribute__((ext_vector_type(4)));
+        typedef float fv4 __attribute__((ext_vector_type(4)));
+        iv4 r0 = reinterpret_cast<const iv4 *>(ep)[0];
+        fv4 r1 = reinterpret_cast<const fv4 *>(ep)[1], r2 = reinterpret_cast<const fv4 *>(ep)[2];
+        fv4 r3 = reinterpret_cast<const fv4 *>(ep)[3], r4 = reinterpret_cast<const fv4 *>(ep)[4];
+        iv4 r6 = reinterpret_cast<const iv4 *>(ep)[6];
+        asm volatile("" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3), "+v"(r4), "+v"(r6));   /* all six here, whole: not split up and moved to their uses */
+        e.shape = r0.x; e.material = r0.y; e.octree_depth = r0.z; e.root_node = (uint32_t)r0.w;
+        e.aabb_min[0] = r1.x; e.aabb_min[1] = r1.y; e.aabb_min[2] = r1.z; e.tri_first = __float_as_uint(r1.w);
+        e.aabb_max[0] = r2.x; e.aabb_max[1] = r2.y; e.aabb_max[2] = r2.z; e.n_tris = __float_as_uint(r2.w);
+        e.region_min[0] = r3.x; e.region_min[1] = r3.y; e.region_min[2] = r3.z; e.shade_base = __float_as_uint(r3.w);
+        e.region_max[0] = r4.x; e.region_max[1] = r4.y; e.region_max[2] = r4.z; e.has_uvs = __float_as_int(r4.w);
+        e.root_a = (uint32_t)r6.y; e.root_b = (uint32_t)r6.z;
+    }
+    entity_visit<STATS, PREPASS>(sc, L, st, e, ep, masked);
 }
 
 template <bool STATS>
@@ -767,7 +794,7 @@ __device__ __forceinline__ void trace_wave(const PtSceneDev &sc, Lane &L, Stats 
         const int which = (n_ent >= n_node && n_ent >= n_leaf) ? 0 : (!leaf_first ? 1 : 2);
         if (which == 0) {
             if (STATS) st.ent_trips++;
-            if (L.mode == M_ENTITY) { if (STATS) st.ent_lanes++; entity_block<STATS, PREPASS>(sc, L, st); }
+            if (L.mode == M_ENTITY) { if (STATS) st.ent_lanes++; entity_block<STATS, PREPASS, COOP>(sc, L, st); }
         }
         if (which == 1) {
             int trips = 0;

@@ -58,7 +58,8 @@ struct alignas(16) PtEntity {
     float    center[3];
     float    radius;
     int32_t  smooth_shading;
-    int32_t  pad[3];
+    uint32_t root_a, root_b;   /* copy of nodes[root_node]: entering the octree costs no fetch that depends on another */
+    int32_t  pad;
 };
 
 struct PtMaterial {
