@@ -36,7 +36,7 @@ B_TRI = 40                   # one pre-gathered triangle record (v0, e1, e2, id)
 B_SHADE = 64 + 24            # per hit: one shading record (3 normals + 3 uvs) + re-read of the accepted triangle's e1, e2
 B_TEXEL = 3                  # RGB8 texel (gloss: 1, counted as 3 for simplicity -> upper bound below 0.1 % of the total)
 B_ENV = 48                   # bilinear HDRI lookup: 4 texels x 12 B
-B_ENTITY = 128               # entity record + AABB per (segment, entity)
+B_ENTITY = 128               # entity record (112 B, counted as one 128-byte line) per (segment, entity)
 
 
 VALU_PEAK_TFLOPS = 157.3       # fp32 vector peak of one MI355X (256 CUs x 128 lanes x 2 flop x 2.4 GHz)
