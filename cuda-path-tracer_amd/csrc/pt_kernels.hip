@@ -534,10 +534,13 @@ __global__ void __launch_bounds__(kBlock, WAVES) render_kernel(RenderParams P) {
             float xi[4];
             const uint32_t bounce = (meta & kBounceMask) >> kBounceShift;
             rng_block((pxy >> 16) * (uint32_t)W + (pxy & 0xFFFFu), (uint32_t)s_cur, hit ? 1u + bounce : 0u, P.seed, xi);
+            /* both kinds of lane end with a ray to trace (but for a path at the bounce limit): the ray is started once,
+             * after the two branches, so that its set-up is not there twice with copies where the branches join */
+            V3 o = L.o, d = L.d;
+            bool go = true;
             if (hit) {
                 Surface sf;
                 finish_hit(P.sc, L.o, L.d, L.best, sf);
-                V3 o = L.o, d = L.d;
                 shade_hit<STATS>(P.sc, L.best, sf, xi, o, d, atten, result, st);
                 meta += kBounceOne;
                 if (bounce + 1u >= 6u) {   /* src/renderer.cu:99; the lane's next sample starts in the next round */
@@ -545,18 +548,17 @@ __global__ void __launch_bounds__(kBlock, WAVES) render_kernel(RenderParams P) {
                     s_cur++;
                     meta -= 1u;
                     L.mode = M_IDLE;
-                } else {
-                    if (STATS) st.segments++;
-                    lane_start_ray(L, o, d);
-                    if (PREPASS) entity_prepass<STATS>(P.sc, L, st);
+                    go = false;
                 }
             } else {
-                V3 o, d;
                 camera_ray(P.cam, P.camk, (int)(pxy & 0xFFFFu), (int)(pxy >> 16), xi, o, d);
                 atten = mk(1.f, 1.f, 1.f);
                 result = mk(0.f, 0.f, 0.f);
                 meta &= ~kBounceMask;
-                if (STATS) { st.paths++; st.segments++; }
+                if (STATS) st.paths++;
+            }
+            if (go) {
+                if (STATS) st.segments++;
                 lane_start_ray(L, o, d);
                 if (PREPASS) entity_prepass<STATS>(P.sc, L, st);
             }
