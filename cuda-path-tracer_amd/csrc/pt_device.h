@@ -844,7 +844,7 @@ __device__ __forceinline__ void finish_hit(const PtSceneDev &sc, V3 o, V3 d, con
     }
     const float *pf = reinterpret_cast<const float *>(reinterpret_cast<const char *>(sc.tris) + (size_t)(best.rec >> 1) * 16u) + (best.rec & 1u);
     const V3 e1 = mk(pf[6], pf[8], pf[10]), e2 = mk(pf[12], pf[14], pf[16]);
-    sf.normal = normalized(cross3(e1, e2));
+    V3 nv = cross3(e1, e2);               /* the vector that becomes the normal: normalised once, below */
     if (e.has_uvs || e.smooth_shading) {
         const PtShadeRec &sh = sc.shade[e.shade_base + (uint32_t)reinterpret_cast<const int32_t *>(pf - (best.rec & 1u))[18u + (best.rec & 1u)]];
         const float u = best.bu, v = best.bv;
@@ -854,11 +854,11 @@ __device__ __forceinline__ void finish_hit(const PtSceneDev &sc, V3 o, V3 d, con
             sf.v = (u * sh.uv1[1] + v * sh.uv2[1]) + w * sh.uv0[1];
         }
         if (e.smooth_shading) {
-            V3 n = mk((u * sh.n1[0] + v * sh.n2[0]) + w * sh.n0[0], (u * sh.n1[1] + v * sh.n2[1]) + w * sh.n0[1],
-                      (u * sh.n1[2] + v * sh.n2[2]) + w * sh.n0[2]);
-            sf.normal = normalized(n);
+            nv = mk((u * sh.n1[0] + v * sh.n2[0]) + w * sh.n0[0], (u * sh.n1[1] + v * sh.n2[1]) + w * sh.n0[1],
+                    (u * sh.n1[2] + v * sh.n2[2]) + w * sh.n0[2]);
         }
     }
+    sf.normal = normalized(nv);
 }
 
 /* ------------------------------------------------------------------ RNG: Philox4x32-10 */
