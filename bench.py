@@ -72,6 +72,9 @@ def stamped_profile(name, workload_name, world):
 
     if world != 1:
         return None
+    wl = workload_name.split()[0]
+    if wl != "hcandersen":          # the headline workload's files have the plain names
+        name = name.replace(".json", f"_{wl}.json")
     try:
         with open(os.path.join(REPO, "profiles", "r2", name)) as f:
             d = json.load(f)
@@ -79,6 +82,7 @@ def stamped_profile(name, workload_name, world):
         return None
     if d.get("workload") != workload_name or not d.get("source_hash") or d.get("source_hash") != ptamd.source_hash():
         return None
+    d["_file"] = "profiles/r2/" + name
     return d
 
 
@@ -236,13 +240,13 @@ def main():
            "fetch_bytes_per_launch": fetch_b, "write_bytes_per_launch": write_b,
            "traffic_frac": round(traffic / k_s / 1e9 / HBM_PEAK_GBPS, 4) if traffic and k_ms > 0 else None,
            "write_amplification": round(write_b / partial_bytes, 2) if write_b else None,
-           "traffic_source": "profiles/r2/traffic.json" if tj else None}
+           "traffic_source": tj["_file"] if tj else None}
     fj = stamped_profile("fetch_by_array.json", workload_name, world)
     if fj and k_ms > 0:
         # which array the memory-side fetches belong to (probe builds that keep one array in cache): the octree's nodes and
         # triangle records are in "geometry_and_scratch" together with the reloads of spilled registers
         hbm["fetch_GBps_by_array"] = {k: round(fj[k] / k_s / 1e9, 1) for k in ("textures", "hdri", "geometry_and_scratch")}
-        hbm["fetch_by_array_source"] = "profiles/r2/fetch_by_array.json"
+        hbm["fetch_by_array_source"] = fj["_file"]
     # (d) what binds: vector-instruction issue.  frac = (share of the time the SIMDs' vector units are busy) x (mean share
     # of the 64 lanes active in a vector instruction) = share of the chip's lane slots that do work
     n_mesh = sum(1 for e in desc["entities"] if e["kind"] == "mesh")
@@ -253,14 +257,14 @@ def main():
     frac = round(min(busy, 1.0) * lanes, 4) if busy is not None and lanes is not None else None
     roofline = {"bound": "valu-issue", "achieved": round(frac * LANE_OP_PEAK_T, 2) if frac is not None else None,
                 "peak": round(LANE_OP_PEAK_T, 2), "unit": "Tlane-op/s", "frac": frac,
-                "valu_busy": busy, "active_lane_fraction": lanes, "pmc_source": "profiles/r2/pmc_ratios.json" if pj else None,
+                "valu_busy": busy, "active_lane_fraction": lanes, "pmc_source": pj["_file"] if pj else None,
                 "traffic": traffic, "kernel": "render_kernel", "kernel_ms": round(k_ms, 3),
                 "hbm": hbm,
                 "cache_demand": {"bytes_per_launch": alg_bytes, "GBps": round(alg_bytes / k_s / 1e9, 1) if k_ms > 0 else None,
                                  "GBps_by_array": fetch_demand},
                 "useful_fp32": {"TFLOPs": round(tflops, 3), "frac_of_vector_peak": round(tflops / VALU_PEAK_TFLOPS, 5),
                                 "flops_per_launch": int(alg_flops)}}
-    pmc = {k: v for k, v in pj.items() if k not in ("workload", "source_hash")} if pj else None
+    pmc = {k: v for k, v in pj.items() if k not in ("workload", "source_hash", "_file")} if pj else None
 
     cpu_baseline = None
     parity = None

@@ -352,6 +352,7 @@ int pt_scene_add_sphere(pt_scene *scene, const float center[3], float radius, in
 int pt_scene_set_hdri(pt_scene *scene, const float *rgb, int w, int h, float exposure, float contrast, float rot_offset, int smooth) {
     if (!scene) PT_FAIL("pt_scene_set_hdri: null argument");
     if (!rgb || w <= 0 || h <= 0) PT_FAIL("pt_scene_set_hdri: empty image");
+    if ((unsigned long long)w * (unsigned long long)h * 12ull >= (1ull << 32)) PT_FAIL("pt_scene_set_hdri: image of 4 GiB or more (texels are addressed by 32-bit byte offsets)");
     if (!(rot_offset >= 0.0f)) PT_FAIL("pt_scene_set_hdri: rotation must be >= 0");   /* src/scene.cu:53 */
     scene->hdri.assign(rgb, rgb + (size_t)w * h * 3);
     scene->hdri_w = w; scene->hdri_h = h;
@@ -463,6 +464,8 @@ int pt_scene_commit(pt_scene *scene) {
     if (scene->has_hdri && upload_vec(scene, scene->hdri, &d.hdri, &scene->bytes_hdri)) return 1;
     d.n_entities = (int32_t)ents.size();
     d.hdri_w = scene->hdri_w; d.hdri_h = scene->hdri_h;
+    d.hdri_w_f = (float)scene->hdri_w; d.hdri_h_f = (float)scene->hdri_h;
+    d.hdri_xmax_f = (float)(scene->hdri_w - 1); d.hdri_ymax_f = (float)(scene->hdri_h - 1);
     d.has_hdri = scene->has_hdri ? 1 : 0;
     d.use_smooth_hdri = scene->hdri_smooth ? 1 : 0;
     d.hdri_exposure = scene->hdri_exposure;

@@ -106,24 +106,28 @@ __device__ __forceinline__ V3 sample_hdri(const PtSceneDev &sc, V3 v, Stats &st)
     x_c += sc.hdri_rot_offset;
     x_c = __builtin_amdgcn_fractf(x_c);      /* fmodf(x, 1) for x >= 0: both are exact */
 #ifdef PT_PROBE_HDRI0
-    const int W = 2, H = 2;
+    const uint32_t W = 2u, H = 2u;
+    const float Wf = 2.0f, Hf = 2.0f, xmax = 1.0f, ymax = 1.0f;
 #else
-    const int W = sc.hdri_w, H = sc.hdri_h;
+    const uint32_t W = (uint32_t)sc.hdri_w, H = (uint32_t)sc.hdri_h;
+    const float Wf = sc.hdri_w_f, Hf = sc.hdri_h_f, xmax = sc.hdri_xmax_f, ymax = sc.hdri_ymax_f;
 #endif
-    const float *cols = sc.hdri;
+    /* texel (x, y): a 32-bit byte offset from the image's base (images of 4 GiB and more are refused when they are set) */
+    const char *cols = reinterpret_cast<const char *>(sc.hdri);
+#define PT_HDRI_TEXEL(x, y) reinterpret_cast<const float *>(cols + ((y) * W + (x)) * 12u)
+    const uint32_t x_l = (uint32_t)(int)__builtin_amdgcn_fmed3f(x_c * Wf, 0.0f, xmax);      /* to_index(x_c * W, W) */
+    const uint32_t y_l = (uint32_t)(int)__builtin_amdgcn_fmed3f(y_c * Hf, 0.0f, ymax);
     V3 res;
     if (!sc.use_smooth_hdri) {
-        const int x_i = to_index(x_c * (float)W, W), y_i = to_index(y_c * (float)H, H);
-        const float *p = cols + 3 * ((size_t)y_i * W + x_i);
+        const float *p = PT_HDRI_TEXEL(x_l, y_l);
         res = mk(p[0], p[1], p[2]);
     } else {
-        const int x_l = to_index(x_c * (float)W, W), y_l = to_index(y_c * (float)H, H);
         /* (x_l + 1) % W with x_l in [0, W): a wrap, not a division */
-        const int x_r = x_l + 1 == W ? 0 : x_l + 1, y_r = y_l + 1 == H ? 0 : y_l + 1;
-        const float xw = fminf(fmaxf(x_c * (float)W - (float)x_l, 0.0f), 1.0f);
-        const float yw = fminf(fmaxf(y_c * (float)H - (float)y_l, 0.0f), 1.0f);
-        const float *ul = cols + 3 * ((size_t)y_l * W + x_l), *ur = cols + 3 * ((size_t)y_l * W + x_r);
-        const float *ll = cols + 3 * ((size_t)y_r * W + x_l), *lr = cols + 3 * ((size_t)y_r * W + x_r);
+        const uint32_t x_r = x_l + 1u == W ? 0u : x_l + 1u, y_r = y_l + 1u == H ? 0u : y_l + 1u;
+        const float xw = fminf(fmaxf(x_c * Wf - (float)(int)x_l, 0.0f), 1.0f);
+        const float yw = fminf(fmaxf(y_c * Hf - (float)(int)y_l, 0.0f), 1.0f);
+        const float *ul = PT_HDRI_TEXEL(x_l, y_l), *ur = PT_HDRI_TEXEL(x_r, y_l);
+        const float *ll = PT_HDRI_TEXEL(x_l, y_r), *lr = PT_HDRI_TEXEL(x_r, y_r);
         /* bilerp of src/math_util.cuh:20-24: lerp(lerp(ul,ll,v), lerp(ur,lr,v), u) */
         float o[3];
         for (int k = 0; k < 3; k++) {
@@ -133,6 +137,7 @@ __device__ __forceinline__ V3 sample_hdri(const PtSceneDev &sc, V3 v, Stats &st)
         }
         res = mk(o[0], o[1], o[2]);
     }
+#undef PT_HDRI_TEXEL
     if (sc.hdri_contrast != 1.0f) {          /* powf(x, 1) == x */
         res.x = hdri_pow(res.x, sc.hdri_contrast);
         res.y = hdri_pow(res.y, sc.hdri_contrast);

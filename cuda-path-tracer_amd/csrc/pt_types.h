@@ -83,6 +83,9 @@ struct PtSceneDev {
     const float      *hdri;    /* h x w x 3 */
     int32_t n_entities;
     int32_t hdri_w, hdri_h;
+    float   hdri_w_f, hdri_h_f, hdri_xmax_f, hdri_ymax_f;   /* (float)w, (float)h, (float)(w - 1), (float)(h - 1): made once on the
+                                                             * host; converted in the kernel they are loop invariants that get
+                                                             * hoisted out of its work loop and spilled */
     int32_t has_hdri, use_smooth_hdri;
     float   hdri_exposure, hdri_contrast, hdri_rot_offset;
     int32_t max_depth;         /* deepest octree in the scene: sizes the per-lane stack */

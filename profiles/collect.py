@@ -31,13 +31,16 @@ def newest(pattern):
 
 shutil.copy(newest(f"{prof}/trace/*/*kernel_stats.csv"), f"{out}/kernel_stats_{tag}.csv")
 shutil.copy(f"{prof}/trace_bench.json", f"{out}/bench_line_{tag}.json")
-shutil.copy(os.path.join(root, "gpurun_out", f"bench_default_{tag}.json"), f"{out}/bench_default_{tag}.json")
+if os.path.exists(os.path.join(root, "gpurun_out", f"bench_default_{tag}.json")):
+    shutil.copy(os.path.join(root, "gpurun_out", f"bench_default_{tag}.json"), f"{out}/bench_default_{tag}.json")
 with open(f"{out}/summary_{tag}.json", "w") as f:
     subprocess.run([sys.executable, os.path.join(root, "profiles", "summarize.py"), prof], stdout=f, check=True)
 
 bench = json.load(open(f"{out}/bench_line_{tag}.json"))
 workload = bench["config"]["workload"]
 source_hash = bench["library_source_hash"]
+# the headline workload's counter files have the plain names; the other configurations' carry the workload's name
+suffix = "" if workload.split()[0] == "hcandersen" else "_" + workload.split()[0]
 
 
 def timed_kernel_counters(passes):
@@ -70,7 +73,7 @@ json.dump({
     "FETCH_SIZE_KB": fetch_kb, "WRITE_SIZE_KB": write_kb,
     "correction": "FETCH_SIZE x2 on gfx950 (128-byte requests tallied as 64 bytes); calibrated for streaming reads, this kernel "
                   "gathers: treat as +-2x",
-    "traffic_bytes_per_launch": traffic}, open(f"{out}/traffic.json", "w"), indent=1)
+    "traffic_bytes_per_launch": traffic}, open(f"{out}/traffic{suffix}.json", "w"), indent=1)
 
 acc, kname = timed_kernel_counters(["sq1", "sq2", "tcc1", "tcc2", "tcp"])
 g = acc["GRBM_GUI_ACTIVE"] / 8
@@ -86,17 +89,17 @@ json.dump({
     "waitcnt_over_wave_cycles": round(acc["SQ_WAIT_ANY"] / acc["SQ_WAVE_CYCLES"], 3),
     "l2_hit_rate": round(acc["TCC_HIT_sum"] / acc["TCC_REQ_sum"], 3),
     "l1_miss_rate": round(acc["TCP_TCC_READ_REQ_sum"] / acc["TCP_TOTAL_CACHE_ACCESSES_sum"], 3),
-    "waves_per_simd": int(kname.split(",")[1].strip(" >"))}, open(f"{out}/pmc_ratios.json", "w"), indent=1)
+    "waves_per_simd": int(kname.split(",")[1].strip(" >"))}, open(f"{out}/pmc_ratios{suffix}.json", "w"), indent=1)
 
 cfgs = []
-for w in ("cornellbox", "teapot", "dragon", "hcandersen", "synthetic"):
+for w in () if suffix else ("cornellbox", "teapot", "dragon", "hcandersen", "synthetic"):
     p = os.path.join(root, "gpurun_out", f"cfg_{w}.json")
     if os.path.exists(p):
         cfgs.append(json.load(open(p)))
 if cfgs:
     json.dump(cfgs, open(f"{out}/configs_{tag}.json", "w"), indent=1)
 
-print("traffic TB", traffic / 1e12, json.load(open(f"{out}/pmc_ratios.json")))
+print("traffic TB", traffic / 1e12, json.load(open(f"{out}/pmc_ratios{suffix}.json")))
 for line in open(f"{out}/kernel_stats_{tag}.csv"):
     if "ptamd" in line:
         print(line.strip()[:140])
@@ -106,5 +109,5 @@ print("traced bench", bench["value"], bench["roofline"]["kernel_ms"])
 
 # memory-side fetch bytes by array (profiles/fetch_attr.sh <tag>), if that run exists
 fa = os.path.join(root, "gpurun_out", f"fetch_{tag}", "fetch_by_array.json")
-if os.path.exists(fa):
+if os.path.exists(fa) and not suffix:
     shutil.copy(fa, f"{out}/fetch_by_array.json")
