@@ -263,6 +263,57 @@ Rows3 euler_zyx(const vec3 &rot) {
 
 }  // namespace
 
+bool AABB::intersects_triangle(vec3 u0, vec3 u1, vec3 u2) {
+    const float lo[3] = {min.x, min.y, min.z}, hi[3] = {max.x, max.y, max.z};
+    const float a[3] = {u0.x, u0.y, u0.z}, b[3] = {u1.x, u1.y, u1.z}, c[3] = {u2.x, u2.y, u2.z};
+    int overlaps = 0;
+    PT_CHECK(pt_box_intersects_triangle(lo, hi, a, b, c, 0, &overlaps));
+    return overlaps != 0;
+}
+
+/* ================================================================== pointer octree */
+Octree::~Octree() {
+    for (Octree *child : children) delete child;
+}
+
+void Octree::pretty_print(int child_nr) {       /* src/octree.cu:9-19: one line per node, indented by depth */
+    printf("%*s[%d] : ", 2 * depth, "", child_nr);
+    for (int t : triangle_indices) printf("%d, ", t);
+    printf("\n");
+    for (int i = 0; i < 8; i++)
+        if (children[i]) children[i]->pretty_print(i);
+}
+
+void Octree::insert_triangle(vec3 v0, vec3 v1, vec3 v2, size_t triangle_idx) {     /* src/octree.cu:83-127 */
+    if (depth == leaf_depth) {
+        triangle_indices.push_back((int)triangle_idx);
+        n_triangle_indices++;
+        return;
+    }
+    /* child i takes the upper half in x / y / z where bit 2 / 1 / 0 of i is set; its box is padded again by the
+     * AABB constructor, like every box of the tree */
+    const vec3 lo = region.min, hi = region.max;
+    const vec3 mid(0.5f * (lo.x + hi.x), 0.5f * (lo.y + hi.y), 0.5f * (lo.z + hi.z));
+    bool placed = false;
+    for (int i = 0; i < 8; i++) {
+        const bool ux = i & 4, uy = i & 2, uz = i & 1;
+        AABB box(vec3(ux ? mid.x : lo.x, uy ? mid.y : lo.y, uz ? mid.z : lo.z),
+                 vec3(ux ? hi.x : mid.x, uy ? hi.y : mid.y, uz ? hi.z : mid.z));
+        if (!box.intersects_triangle(v0, v1, v2)) continue;
+        placed = true;
+        if (!children[i]) children[i] = new Octree(box, depth + 1, leaf_depth);
+        children[i]->insert_triangle(v0, v1, v2, triangle_idx);
+    }
+    if (!placed) std::cout << "Miss triangle!" << std::endl;
+}
+
+void Octree::insert_triangles(Vertex *vertices, Triangle *triangles, size_t n_triangles) {     /* src/octree.cu:132-142 */
+    for (size_t t = 0; t < n_triangles; t++) {
+        const Triangle &tri = triangles[t];
+        insert_triangle(vertices[tri.idx_a].position, vertices[tri.idx_b].position, vertices[tri.idx_c].position, t);
+    }
+}
+
 void AABB::recalculate(Vertex *vertices, int n_vertices) {      /* src/aabb.cu:7-22: padded bounds of the vertices */
     Extent ext;
     for (const Vertex *v = vertices; v != vertices + n_vertices; ++v) ext.include(v->position);

@@ -141,8 +141,34 @@ struct AABB {
         this->max = max + vec3(AABB_PADDING, AABB_PADDING, AABB_PADDING);
     }
     void recalculate(Vertex *vertices, int n_vertices);
+    /* separating-axis test of the box against a triangle (src/aabb.cu:64-120), as the octree builder uses it */
+    bool intersects_triangle(vec3 u0, vec3 u1, vec3 u2);
     vec3 min;
     vec3 max;
+};
+
+/* The reference's pointer octree (src/geometry.cuh:93-133, src/octree.cu:9-142) for code that builds or inspects a
+ * tree by hand: same constructor, members and insertion semantics (a triangle goes into every child whose padded
+ * box it overlaps; leaves, at depth `leaf_depth`, list triangle indices in insertion order).  Rendering does not use
+ * it: Entity::construct_octree builds the same tree level by level inside the library and flattens it for the GPU,
+ * and the tests compare the two node for node.  The leaf depth is the reference's MAX_OCTREE_DEPTH unless given. */
+struct Octree {
+    Octree(AABB aabb, int depth, int leaf_depth = MAX_OCTREE_DEPTH) : children(), depth(depth), region(aabb), leaf_depth(leaf_depth) {}
+    ~Octree();
+    Octree(const Octree &) = delete;
+    Octree &operator=(const Octree &) = delete;
+    void pretty_print(int child_nr);
+    void copy_to_device() {}                         /* the flattened tree travels with the scene */
+    void free_from_device() {}
+    void insert_triangle(vec3 v0, vec3 v1, vec3 v2, size_t triangle_idx);
+    void insert_triangles(Vertex *vertices, Triangle *triangles, size_t n_triangles);
+    Octree *children[8];
+    std::vector<int> triangle_indices;
+    int n_triangle_indices = 0;
+    int depth;
+    AABB region;
+    bool on_device = false;
+    int leaf_depth;
 };
 
 class Entity {

@@ -8,12 +8,14 @@
  *   facade_check pnm   <in.ppm|pgm> <channels> <out.bin>
  *   facade_check teapot <utah.obj> <floor.obj> <w> <h> <spp> <out.bin> [octree depth [devices, e.g. 0,0]]   (needs a GPU)
  *   facade_check octree <in.obj> <depth>                                     (prints the tree's shape)
+ *   facade_check ptree <in.obj> <depth> <out.bin>                            (the Octree class's pointer tree, dumped in pre-order)
  *   facade_check post  <w> <h> <out.bin>                                     (needs a GPU)
  */
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <vector>
 
 #include "path_tracer.h"
 
@@ -157,7 +159,44 @@ static int cmd_octree(char **argv) {
     return 0;
 }
 
+/* pointer octree built through the Octree class (root = the entity's box at depth 0, as Entity::construct_octree
+ * roots it in the reference, src/entity.cu:167-170), written in the pre-order word format of pt_scene_octree_dump:
+ * per node {depth, slot, child mask (inner) or 0, 0 (inner) or triangle count, triangle indices...} */
+static void dump_pointer_tree(const Octree *n, int slot, int leaf_depth, std::vector<int32_t> &out) {
+    int mask = 0;
+    for (int i = 0; i < 8; i++) mask |= n->children[i] ? 1 << i : 0;
+    out.push_back(n->depth); out.push_back(slot);
+    if (n->depth == leaf_depth) {
+        out.push_back(0); out.push_back((int32_t)n->triangle_indices.size());
+        for (int t : n->triangle_indices) out.push_back(t);
+        return;
+    }
+    out.push_back(mask); out.push_back(0);
+    for (int i = 0; i < 8; i++)
+        if (n->children[i]) dump_pointer_tree(n->children[i], i, leaf_depth, out);
+}
+
+static int cmd_ptree(char **argv) {
+    Material m;
+    Entity e(argv[2], &m);
+    const int leaf_depth = atoi(argv[3]);
+    Octree root(e.bounds(), 0, leaf_depth);
+    root.insert_triangles(const_cast<Vertex *>(e.vertex_data()), const_cast<Triangle *>(e.triangle_data()), e.triangle_count());
+    std::vector<int32_t> words;
+    dump_pointer_tree(&root, 0, leaf_depth, words);
+    FILE *f = fopen(argv[4], "wb");
+    if (!f) return 1;
+    put(f, words.data(), words.size() * sizeof(int32_t));
+    fclose(f);
+    AABB unit(vec3(0.0f), vec3(1.0f));          /* AABB::intersects_triangle on its own: one overlap, one miss */
+    const bool in = unit.intersects_triangle(vec3(0.2f, 0.2f, 0.2f), vec3(0.8f, 0.3f, 0.2f), vec3(0.3f, 0.9f, 0.4f));
+    const bool out = unit.intersects_triangle(vec3(2.0f, 2.0f, 2.0f), vec3(3.0f, 2.0f, 2.0f), vec3(2.0f, 3.0f, 2.0f));
+    printf("words %zu overlap %d miss %d\n", words.size(), (int)in, (int)out);
+    return 0;
+}
+
 int main(int argc, char **argv) {
+    if (argc == 5 && !strcmp(argv[1], "ptree")) return cmd_ptree(argv);
     if (argc >= 4 && !strcmp(argv[1], "mesh")) return cmd_mesh(argc, argv);
     if (argc == 4 && !strcmp(argv[1], "hdr")) return cmd_hdr(argv);
     if (argc == 5 && !strcmp(argv[1], "pnm")) return cmd_pnm(argv);

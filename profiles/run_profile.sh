@@ -11,8 +11,8 @@ mkdir -p $out
 cd $root
 # the kernel-trace pass runs the benchmark's default command line, so its per-kernel average is
 # directly comparable with the HIP-event time in the bench line; the counter passes run the same
-# workload at its full sample count (the launch the bench times), one timed step (PMC_ARGS overrides)
-args="--no-cpu-baseline ${PMC_ARGS:---steps 1 --warmup 0}"
+# workload (the same bench arguments) at its full sample count (the launch the bench times), one timed step (PMC_ARGS overrides)
+args="--no-cpu-baseline $* ${PMC_ARGS:---steps 1 --warmup 0}"
 timeout -s KILL 400 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python3 bench.py $* > $out/trace_bench.json 2> $out/trace.err || { echo "trace pass failed"; tail -5 $out/trace.err; exit 1; }
 pass() {
   name=$1; shift

@@ -195,6 +195,24 @@ def test_runtime_octree_depth_through_the_class_api(pt):
     assert r.returncode != 0 and "depth must be in" in r.stderr
 
 
+@pytest.mark.parametrize("depth", [3, 6])
+def test_pointer_octree_class_equals_the_flat_tree(pt, tmp_path, depth):
+    """The Octree class of the host API (the reference's pointer tree, src/geometry.cuh:93-133, filled triangle by
+    triangle with insert_triangles as src/entity.cu:167-170 does) against the library's level-by-level builder:
+    the same nodes, child slots and leaf triangle lists in the same order; AABB::intersects_triangle answers."""
+    from ptamd import scenes as S
+
+    out = tmp_path / "ptree.bin"
+    r = _run("ptree", TEAPOT, depth, out)
+    assert r.returncode == 0, r.stderr
+    words = np.fromfile(out, dtype=np.int32)
+    pos, tri, _, _ = S.load_obj(TEAPOT)
+    sc = pt.Scene(-1)
+    flat = sc.octree_dump(sc.add_mesh(pos, tri, sc.add_material(), octree_depth=depth))
+    assert words.shape == flat.shape and (words == flat).all()
+    assert r.stdout.split() == ["words", str(len(flat)), "overlap", "1", "miss", "0"]
+
+
 @pytest.mark.gpu
 def test_renderer_depth_nine_and_two_device_render(pt, scenes, tmp_path):
     """Renderer::render with an octree of depth 9 requested through the class API, on one GPU and as a
