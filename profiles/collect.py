@@ -69,7 +69,7 @@ traffic = int(fetch_kb * 1024 * 2 + write_kb * 1024)
 json.dump({
     "workload": workload, "kernel": kname, "source_hash": source_hash,
     "source": f"rocprofv3 --pmc FETCH_SIZE TCC_HIT_sum / --pmc WRITE_SIZE TCC_MISS_sum TCC_REQ_sum (separate passes) over `python3 bench.py "
-              f"--no-cpu-baseline --steps 1 --warmup 0`, profiles/run_profile.sh {tag}; per dispatch of the timed kernel",
+              f"--no-cpu-baseline --workload {workload.split()[0]} --steps 1 --warmup 0`, profiles/run_profile.sh {tag}; per dispatch of the timed kernel",
     "FETCH_SIZE_KB": fetch_kb, "WRITE_SIZE_KB": write_kb,
     "correction": "FETCH_SIZE x2 on gfx950 (128-byte requests tallied as 64 bytes); calibrated for streaming reads, this kernel "
                   "gathers: treat as +-2x",
