@@ -80,6 +80,10 @@ def test_host_only_scene_rejects_commit_and_bad_arguments(pt, teapot):
         sc.octree_info(e)
     with pytest.raises(pt.PtError, match="rotation"):
         sc.set_hdri(np.zeros((2, 2, 3), np.float32), rot=-0.5)
+    # an environment map of 4 GiB or more is refused before a byte of it is read (texels are addressed by 32-bit offsets)
+    tiny = np.zeros((2, 2, 3), np.float32)
+    with pytest.raises(pt.PtError, match="4 GiB"):
+        pt.check(sc.L.pt_scene_set_hdri(sc.h, tiny.ctypes.data, 20000, 18000, 1.0, 1.0, 0.0, 0))
     sc.close()
 
 
