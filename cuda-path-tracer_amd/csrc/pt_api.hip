@@ -70,7 +70,7 @@ struct pt_scene {
     bool heavy = false;        /* traversal-dominated scene: render with the many-waves build of the kernel */
     int quorum = 12;           /* finished lanes per wave that make it leave the geometry blocks to shade / refill */
     int leaf_quota = 20;       /* triangle runs waiting per wave at which it tests them before walking on */
-    bool build_fixed = false, quorum_fixed = false;   /* set by the caller or the environment: commit keeps them */
+    bool build_fixed = false, quorum_fixed = false, leaf_quota_fixed = false;   /* set by the caller or the environment: commit keeps them */
     PtSceneDev dev{};
     std::vector<void *> allocs;
     uint64_t bytes_nodes = 0, bytes_tris = 0, bytes_shade = 0, bytes_tex = 0, bytes_hdri = 0;
@@ -491,10 +491,14 @@ int pt_scene_commit(pt_scene *scene) {
         bool textured = false;
         for (const MaterialHost &m : scene->materials)
             for (int k = 0; k < 4; k++) textured = textured || !m.maps[k].empty();
+        /* an octree so deep that its LDS stacks leave room for three waves per SIMD only: fewer waves cover the round's
+         * fetches, so it should come less often (20 M triangles at depth 9, quorum x leaf quota: 48 x 12 is +2 % on 40 x 20) */
+        const bool few_waves = scene->heavy && render_workgroups_per_cu(max_depth, true) < 4;
         if (max_depth == 0) scene->quorum = 62;
-        else if (scene->heavy) scene->quorum = textured ? 48 : 40;
+        else if (scene->heavy) scene->quorum = (textured || few_waves) ? 48 : 40;
         else scene->quorum = textured ? 40 : 12;
     }
+    if (!scene->leaf_quota_fixed) scene->leaf_quota = (scene->heavy && render_workgroups_per_cu(max_depth, true) < 4) ? 12 : 20;
     if (const char *k = getenv("PTAMD_QUORUM")) {
         const int q = atoi(k);
         if (q >= 1 && q <= 64) { scene->quorum = q; scene->quorum_fixed = true; }
@@ -502,7 +506,7 @@ int pt_scene_commit(pt_scene *scene) {
 
     if (const char *k = getenv("PTAMD_LEAF_QUOTA")) {
         const int q = atoi(k);
-        if (q >= 1 && q <= 65) scene->leaf_quota = q;
+        if (q >= 1 && q <= 65) { scene->leaf_quota = q; scene->leaf_quota_fixed = true; }
     }
 
     PT_HIP(hipMalloc((void **)&scene->d_tickets, (kMaxQueues + 1) * sizeof(uint32_t)));

@@ -63,7 +63,7 @@ CASES = {
     # name: (builder kwargs, waves per SIMD the heavy build must be instantiated for, quorum picked at commit)
     "hcandersen-4wave": (dict(kind="hcandersen", n_tris=60000, octree_depth=6, tex_res=256, hdri_res=(512, 256)), 4, 48),
     "dragon-4wave": (dict(kind="dragon", n_tris=140000, octree_depth=7, hdri_res=(512, 256)), 4, 40),
-    "synthetic-3wave": (dict(kind="synthetic", n_tris=80000, octree_depth=9, hdri_res=(512, 256)), 3, 40),
+    "synthetic-3wave": (dict(kind="synthetic", n_tris=80000, octree_depth=9, hdri_res=(512, 256)), 3, 48),
 }
 
 
