@@ -133,8 +133,16 @@ def main():
         raise SystemExit(f"{world} ranks but {n_dev} GPU(s): RCCL needs one GPU per rank (use --backend gloo to rehearse on fewer)")
     dev = local_rank % n_dev
     torch.cuda.set_device(dev)
-    if world > 1:
+    # PTAMD_FORCE_DIST=1: a process group even for one rank, so that the collective calls of the N > 1 path (RCCL
+    # reduce, barrier, all_reduce) run on a box with a single GPU
+    use_dist = world > 1 or os.environ.get("PTAMD_FORCE_DIST") == "1"
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if "MASTER_PORT" not in os.environ:
+            s = socket.socket()
+            s.bind(("127.0.0.1", 0))
+            os.environ["MASTER_PORT"] = str(s.getsockname()[1])
+            s.close()
         if args.backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev))
         else:
@@ -163,7 +171,7 @@ def main():
         split.zero_()
         cnt = scene.render_accumulate(cam, 1337, s_begin, s_end, n_split, split.data_ptr(), want_counters, stream)
         ptamd.check(L.pt_compound_buffers(dev, split.data_ptr(), local_sum.data_ptr(), n_pixels, n_split, stream))
-        if world > 1:
+        if use_dist:
             if args.backend == "nccl":
                 dist.reduce(local_sum, dst=0, op=dist.ReduceOp.SUM)
             else:
@@ -174,7 +182,7 @@ def main():
         return cnt
 
     def fence():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -200,7 +208,7 @@ def main():
     cdev = f"cuda:{dev}" if args.backend == "nccl" else "cpu"
     t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
     cvec = torch.tensor([counters[k] for k in ptamd.COUNTER_NAMES], dtype=torch.float64, device=cdev)
-    if world > 1:
+    if use_dist:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dist.all_reduce(cvec, op=dist.ReduceOp.SUM)
     elapsed = float(t.item())
@@ -324,10 +332,10 @@ def main():
             "roofline": roofline, "pmc": pmc, "cpu_baseline": cpu_baseline, "parity_vs_oracle": parity,
             "post_chain_ms": None if post_ms is None else round(post_ms, 2),
             "scene_gen_s": round(t_gen, 2), "scene_build_upload_s": round(t_upload, 2),
-            "scene_device_bytes": sbytes, "library_source_hash": ptamd.source_hash(), "backend": args.backend if world > 1 else None,
+            "scene_device_bytes": sbytes, "library_source_hash": ptamd.source_hash(), "backend": args.backend if use_dist else None,
         }
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 
