@@ -15,6 +15,8 @@ octree build, upload and post-processing are reported separately and are not par
 `--gpus N` without a launcher (no WORLD_SIZE in the environment) starts the N ranks itself as child
 processes.  `--backend gloo` (or PTAMD_DIST_BACKEND=gloo) runs the collective over gloo on host
 copies and lets several ranks share one GPU: a rehearsal of the N > 1 path on a one-GPU box.
+PTAMD_FORCE_DIST=1 makes a single rank set up its process group and run the same collective calls
+(over RCCL with the default backend), which is how a one-GPU box exercises that branch.
 
 Prints ONE JSON line on rank 0.
 """
