@@ -14,6 +14,7 @@
 #include <vector>
 
 #include "octree_build.h"
+#include "pt_child_table.h"
 #include "pt_internal.h"
 
 namespace ptamd {
@@ -836,6 +837,13 @@ int pt_box_intersects_triangle(const float bmin[3], const float bmax[3], const f
         mx[k] = pad_box ? bmax[k] + 0.0001f : bmax[k];
     }
     *overlaps = box_intersects_triangle(mn, mx, v0, v1, v2) ? 1 : 0;
+    return 0;
+}
+
+int pt_child_tables(uint8_t *set_out, uint8_t *mir_out) {
+    static constexpr ChildTables t = make_child_tables();
+    if (set_out) memcpy(set_out, t.set, sizeof t.set);
+    if (mir_out) memcpy(mir_out, t.mir, sizeof t.mir);
     return 0;
 }
 

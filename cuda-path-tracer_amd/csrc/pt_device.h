@@ -35,6 +35,7 @@
 #include <float.h>
 #include <stdint.h>
 
+#include "pt_child_table.h"
 #include "pt_types.h"
 
 namespace ptamd {
@@ -127,75 +128,68 @@ struct Lane {
  * parameters of the current child (per axis: the node's t1 if the child's bit is set, else tM, the
  * argument table of dgf:178-187): the axis with the smallest exit parameter gets its bit set, or
  * the node is left when that bit is already set.  Bits are only ever set, so the sequence has at
- * most four members and does not depend on which children exist -- it is evaluated once, on entry.
- * Each step adds a bit to the child number, so the members come in ascending (mirrored) child number and
- * the list is a set:
+ * most four members and does not depend on which children exist; each step adds a bit to the child number, so the
+ * members come in ascending (mirrored) child number and the list is a set:
  *   bits  0..7   go:  child c (mirrored numbering) is a member, exists in the tree and passes the entry
  *                test of dgf:142
  *   bits  8..15  rej: child c is a member and exists but fails that test (entered and left at once: it
  *                only counts; kept in counting builds)
  *   bits 24..31  the node's child mask
- * Steps after the one that leaves the node repeat the last member.
+ * Which children are members follows from ten comparisons between the interval's parameters (pt_child_table.h has
+ * the derivation): they are shifted into a key through the carry flag and the set is read from a table in LDS, and
+ * so is the node's child mask in the ray's mirrored numbering (`tabs`: ChildTables at the start of the workgroup's LDS).
  */
 template <bool STATS>
 __device__ __forceinline__ uint32_t child_list(float t0x, float t0y, float t0z, float t1x, float t1y, float t1z, uint32_t nm,
-                                               int a) {
+                                               int a, const uint8_t *tabs) {
     const float tMx = 0.5f * (t0x + t1x), tMy = 0.5f * (t0y + t1y), tMz = 0.5f * (t0z + t1z);
     /* find_first_node (dgf:95-110): the entry plane is the one with the largest t0, and every OTHER axis whose mid plane
      * lies before the entry point te starts with its bit set.  The entry axis needs no special case: its own mid
      * parameter cannot lie before te = its t0, because t0 <= t1 on every axis (the ray was mirrored to run along
      * +x +y +z) and 0.5 * (t0 + t1) rounds monotonically, so tM >= t0; with ties for the largest t0 the tied axes all
-     * have tM >= te.  So: te = max(t0), bit = tM < te on all three axes.
-     * The state of the walk is then one flag per axis (its bit in the child number) and that axis' exit parameter
-     * (t1 once the bit is set, tM before), so that a step is three comparisons and three selects; the flag logic is
-     * mask arithmetic on the scalar unit */
+     * have tM >= te.  So: te = max(t0), bit = tM < te on all three axes. */
     const float te = fmaxf(fmaxf(t0x, t0y), t0z);
-    /* per axis: bit = tM < te, shifted into the child number through the carry (c = 2 c + bit); exit = bit ? t1 : tM */
-    float ex, ey, ez;
-    uint32_t c = 0u;
-    asm("v_cmp_lt_f32_e32 vcc, %[tMx], %[te]\n\t"
-        "v_cndmask_b32_e32 %[ex], %[tMx], %[t1x], vcc\n\t"
-        "v_addc_co_u32_e32 %[c], vcc, %[c], %[c], vcc\n\t"
+    /* the key: per comparison key = 2 key + (a < b), the flag going from the compare into the addition through VCC.
+     * (The two minima in assembly: the parameters are never NaN, and the compiler would quiet them first.) */
+    uint32_t key = 0u;
+    float myz, mxy;
+    asm("v_min_f32_e32 %[myz], %[t1y], %[t1z]\n\t"
+        "v_min_f32_e32 %[mxy], %[t1x], %[t1y]\n\t"
+        "v_cmp_lt_f32_e32 vcc, %[tMx], %[te]\n\t"
+        "v_addc_co_u32_e32 %[k], vcc, %[k], %[k], vcc\n\t"
         "v_cmp_lt_f32_e32 vcc, %[tMy], %[te]\n\t"
-        "v_cndmask_b32_e32 %[ey], %[tMy], %[t1y], vcc\n\t"
-        "v_addc_co_u32_e32 %[c], vcc, %[c], %[c], vcc\n\t"
+        "v_addc_co_u32_e32 %[k], vcc, %[k], %[k], vcc\n\t"
         "v_cmp_lt_f32_e32 vcc, %[tMz], %[te]\n\t"
-        "v_cndmask_b32_e32 %[ez], %[tMz], %[t1z], vcc\n\t"
-        "v_addc_co_u32_e32 %[c], vcc, %[c], %[c], vcc"
-        : [ex] "=&v"(ex), [ey] "=&v"(ey), [ez] "=&v"(ez), [c] "+v"(c)
+        "v_addc_co_u32_e32 %[k], vcc, %[k], %[k], vcc\n\t"
+        "v_cmp_lt_f32_e32 vcc, %[tMx], %[myz]\n\t"
+        "v_addc_co_u32_e32 %[k], vcc, %[k], %[k], vcc\n\t"
+        "v_cmp_lt_f32_e32 vcc, %[t1x], %[tMy]\n\t"
+        "v_addc_co_u32_e32 %[k], vcc, %[k], %[k], vcc\n\t"
+        "v_cmp_lt_f32_e32 vcc, %[tMy], %[t1z]\n\t"
+        "v_addc_co_u32_e32 %[k], vcc, %[k], %[k], vcc\n\t"
+        "v_cmp_lt_f32_e32 vcc, %[mxy], %[tMz]\n\t"
+        "v_addc_co_u32_e32 %[k], vcc, %[k], %[k], vcc\n\t"
+        "v_cmp_lt_f32_e32 vcc, %[tMx], %[tMy]\n\t"
+        "v_addc_co_u32_e32 %[k], vcc, %[k], %[k], vcc\n\t"
+        "v_cmp_lt_f32_e32 vcc, %[tMx], %[tMz]\n\t"
+        "v_addc_co_u32_e32 %[k], vcc, %[k], %[k], vcc\n\t"
+        "v_cmp_lt_f32_e32 vcc, %[tMy], %[tMz]\n\t"
+        "v_addc_co_u32_e32 %[k], vcc, %[k], %[k], vcc"
+        : [k] "+v"(key), [myz] "=&v"(myz), [mxy] "=&v"(mxy)
         : [tMx] "v"(tMx), [tMy] "v"(tMy), [tMz] "v"(tMz), [te] "v"(te), [t1x] "v"(t1x), [t1y] "v"(t1y), [t1z] "v"(t1z)
         : "vcc");
+    const uint32_t set = tabs[key];
     /* dgf:142, (ex < 0 || ey < 0 || ey < 0): y twice, never z.  The parameters are products of finite differences and
      * clamped reciprocals, never NaN, so "negative" is "bit pattern above -0.0".  A member's ex is the node's t1x when
      * its x bit is set, and the node would not have been entered with a negative t1x (the same test, one level up, or
      * the root's): only tMx can fail, for the four children without the x bit; likewise y */
     const uint32_t rej = (__float_as_uint(tMx) > 0x80000000u ? 0x0Fu : 0u) | (__float_as_uint(tMy) > 0x80000000u ? 0x33u : 0u);
-    uint32_t cs[4];
-    cs[0] = c;
-#pragma unroll
-    for (int i = 0; i < 3; i++) {
-        /* member i = child c, whose exit parameters are (ex, ey, ez) */
-        const bool s1 = ex < ey, s2 = ex < ez, s3 = ey < ez;              /* next_node, dgf:116-126 */
-        /* x wins with ex < ey and ex < ez, y with ey <= ex and ey < ez, z otherwise, i.e. (no NaNs)
-         * with ez <= ex and ez <= ey: written so that the three flags are plain mask arithmetic */
-        const bool sx = s1 && s2, sy = !s1 && s3;
-        const bool sz = !s2 && !s3;
-        /* the node is left when the winning axis' bit is set already.  No flag is kept for that: the exit parameters
-         * do not change in such a step, so every later step picks the same axis again and the remaining members
-         * repeat the last real one -- setting its bit in the set again changes nothing */
-        c |= sx ? 4u : (sy ? 2u : 1u);
-        cs[i + 1] = c;
-        ex = sx ? t1x : ex; ey = sy ? t1y : ey; ez = sz ? t1z : ez;
-    }
     /* Everything above works on the interval alone.  The node's record, fetched at the start of the trip, is first
-     * needed here; the fence and the empty statement after it (which pins the record and the last step's result to
-     * this point) keep the compiler from pulling uses of the record, and with them the wait for the fetch, up into
-     * the steps: +1.5 % on the whole kernel */
+     * needed here; the fence and the empty statement after it (which pins the record to this point) keep the compiler
+     * from pulling uses of the record, and with them the wait for the fetch, up into the comparisons */
     __builtin_amdgcn_sched_barrier(0);
-    asm volatile("" : "+v"(nm), "+v"(cs[3]));
-    uint32_t members = 0u;
-#pragma unroll
-    for (int i = 0; i < 4; i++) members |= __builtin_amdgcn_ubfe(nm, cs[i] ^ (uint32_t)a, 1u) << cs[i];
+    asm volatile("" : "+v"(nm), "+v"(key));
+    const uint32_t members = set & (uint32_t)tabs[kChildSetEntries + (((uint32_t)a << 8) | nm)];
     uint32_t list = (nm << 24) | (members & ~rej);
     if (STATS) list |= (members & rej) << 8;
     return list;
@@ -246,7 +240,7 @@ __device__ __forceinline__ void lane_start_ray(Lane &L, V3 o, V3 d) {
  */
 /* (the block proper, on a view E of the entity's record: the record itself, or a copy of its rows in registers) */
 template <bool STATS, bool PREPASS, typename E>
-__device__ __forceinline__ void entity_visit(const PtSceneDev &sc, Lane &L, Stats &st, const E &e, const PtEntity *ep, bool masked) {
+__device__ __forceinline__ void entity_visit(const PtSceneDev &sc, Lane &L, Stats &st, const E &e, const PtEntity *ep, bool masked, const uint8_t *tabs) {
     const int32_t ei = L.ent;
     L.ent = ei + 1;                       /* default: move on to the next entity, or finish */
     L.mode = next_entity_mode<PREPASS>(sc, L);
@@ -296,12 +290,12 @@ __device__ __forceinline__ void entity_visit(const PtSceneDev &sc, Lane &L, Stat
     L.t0x = t0x; L.t0y = t0y; L.t0z = t0z; L.t1x = t1x; L.t1y = t1y; L.t1z = t1z;
     L.nb = e.root_a;                      /* the root's node record, copied into the entity's */
     L.a = a; L.path = 1u; L.framed = 0u; L.rem = e.octree_depth - 1;
-    L.todo = child_list<STATS>(t0x, t0y, t0z, t1x, t1y, t1z, e.root_b, a);
+    L.todo = child_list<STATS>(t0x, t0y, t0z, t1x, t1y, t1z, e.root_b, a, tabs);
     L.mode = M_NODE;
 }
 
 template <bool STATS, bool PREPASS, bool TOGETHER>
-__device__ __forceinline__ void entity_block(const PtSceneDev &sc, Lane &L, Stats &st) {
+__device__ __forceinline__ void entity_block(const PtSceneDev &sc, Lane &L, Stats &st, const uint8_t *tabs) {
     const bool masked = PREPASS && uses_entity_mask(sc);
     if (masked) {
         const uint32_t left = L.emask >> L.ent;
@@ -313,7 +307,7 @@ __device__ __forceinline__ void entity_block(const PtSceneDev &sc, Lane &L, Stat
      * own, four in a row.  Pays for scenes of one large mesh (+2 % with 871 k triangles); scenes of many small meshes lose by
      * it (box scene -6 %: most trips end at the box test).  (A sphere's centre and radius are fetched in its branch.) */
     const PtEntity *ep = &sc.entities[L.ent];
-    if (!TOGETHER) { entity_visit<STATS, PREPASS>(sc, L, st, *ep, ep, masked); return; }
+    if (!TOGETHER) { entity_visit<STATS, PREPASS>(sc, L, st, *ep, ep, masked, tabs); return; }
     struct { int32_t shape, material, octree_depth; uint32_t root_node; float aabb_min[3]; uint32_t tri_first; float aabb_max[3]; uint32_t n_tris;
              float region_min[3]; uint32_t shade_base; float region_max[3]; int32_t has_uvs; uint32_t root_a, root_b; } e;
     {
@@ -331,7 +325,7 @@ __device__ __forceinline__ void entity_block(const PtSceneDev &sc, Lane &L, Stat
         e.region_max[0] = r4.x; e.region_max[1] = r4.y; e.region_max[2] = r4.z; e.has_uvs = __float_as_int(r4.w);
         e.root_a = (uint32_t)r6.y; e.root_b = (uint32_t)r6.z;
     }
-    entity_visit<STATS, PREPASS>(sc, L, st, e, ep, masked);
+    entity_visit<STATS, PREPASS>(sc, L, st, e, ep, masked, tabs);
 }
 
 template <bool STATS>
@@ -377,7 +371,7 @@ __device__ __forceinline__ void entity_prepass(const PtSceneDev &sc, Lane &L, St
  * on return: it then returns again in its next trip.)
  */
 template <bool STATS, bool PREPASS>
-__device__ __forceinline__ void node_block(const PtSceneDev &sc, Lane &L, Stats &st, float4 *stack, uint32_t *stack1, int stride) {
+__device__ __forceinline__ void node_block(const PtSceneDev &sc, Lane &L, Stats &st, float4 *stack, uint32_t *stack1, int stride, const uint8_t *tabs) {
     if ((L.todo & 0xFFu) == 0u) {
         if (STATS) st.node_visits += __popc((L.todo >> 8) & 0xFFu);
         const uint32_t above = L.framed >> L.rem;              /* bit 0: the parent's slot */
@@ -478,7 +472,7 @@ __device__ __forceinline__ void node_block(const PtSceneDev &sc, Lane &L, Stats 
     stack[L.rem * stride] = s;
     stack1[L.rem * stride] = L.todo;
     asm("v_bitop3_b32 %0, %1, %0, %2 bitop3:0xca" : "+v"(L.path) : "v"(last), "v"((L.path << 3) | (uint32_t)curr));   /* last ? path : path.curr */
-    L.todo = child_list<STATS>(L.t0x, L.t0y, L.t0z, L.t1x, L.t1y, L.t1z, rec.b, L.a);
+    L.todo = child_list<STATS>(L.t0x, L.t0y, L.t0z, L.t1x, L.t1y, L.t1z, rec.b, L.a, tabs);
     asm volatile("v_mov_b32_e32 %0, %1" : "+v"(L.nb) : "v"(rec.a));     /* after the list: the record is used as late as possible */
 }
 
@@ -773,7 +767,7 @@ __device__ __forceinline__ int count_lanes(bool p) {
 #endif
 template <bool STATS, bool LOG, bool COOP, bool PREPASS>
 __device__ __forceinline__ void trace_wave(const PtSceneDev &sc, Lane &L, Stats &st, TriLog &lg, float4 *stack, uint32_t *stack1,
-                                           int stride, int done_quota, int leaf_quota, CoopLds *coop, int lane) {
+                                           int stride, int done_quota, int leaf_quota, CoopLds *coop, int lane, const uint8_t *tabs) {
     static_assert(!(LOG && COOP), "the cooperative leaf phase keeps no test log");
     static_assert(!(PREPASS && COOP), "the entity pre-pass belongs to the builds for small scenes");
     for (;;) {
@@ -792,7 +786,7 @@ __device__ __forceinline__ void trace_wave(const PtSceneDev &sc, Lane &L, Stats 
         const int which = (n_ent >= n_node && n_ent >= n_leaf) ? 0 : (!leaf_first ? 1 : 2);
         if (which == 0) {
             if (STATS) st.ent_trips++;
-            if (L.mode == M_ENTITY) { if (STATS) st.ent_lanes++; entity_block<STATS, PREPASS, COOP>(sc, L, st); }
+            if (L.mode == M_ENTITY) { if (STATS) st.ent_lanes++; entity_block<STATS, PREPASS, COOP>(sc, L, st, tabs); }
         }
         if (which == 1) {
             int trips = 0;
@@ -801,7 +795,7 @@ __device__ __forceinline__ void trace_wave(const PtSceneDev &sc, Lane &L, Stats 
 #pragma unroll
                 for (int u = 0; u < PT_NODE_GROUP; u++) {
                     if (STATS) st.node_trips++;
-                    if (L.mode == M_NODE) { if (STATS) st.node_lanes++; node_block<STATS, PREPASS>(sc, L, st, stack, stack1, stride); }
+                    if (L.mode == M_NODE) { if (STATS) st.node_lanes++; node_block<STATS, PREPASS>(sc, L, st, stack, stack1, stride, tabs); }
                 }
             } while ((trips += PT_NODE_GROUP) < PT_TRIPS && PT_KEEP_NODE * __popcll(__ballot(L.mode == M_NODE)) >= n_node &&
                      !(COOP && __popcll(__ballot(L.mode == M_LEAF)) >= leaf_quota));

@@ -27,7 +27,20 @@ static constexpr int kBlock = 256;
  * workgroup's lanes; the walk pushes at levels 0 .. depth-2 (children of level depth-1 nodes are leaves) */
 __host__ __device__ static inline int stack_levels(int max_depth) { return max_depth > 1 ? max_depth - 1 : 1; }
 
-/* dynamic LDS of a workgroup: the stack frames (16-byte words, then 4-byte words), then one CoopLds per wave */
+/* the node step's look-up tables (pt_child_table.h), made at compile time; every workgroup copies them to the start of its LDS */
+__device__ const ChildTables kChildTablesDev = make_child_tables();
+static constexpr int kTableWords = (int)(sizeof(ChildTables) / 4), kTableQuads = (int)(sizeof(ChildTables) / 16);
+static_assert(sizeof(ChildTables) % 16 == 0, "the stack frames behind the tables are 16-byte words");
+
+__device__ __forceinline__ void load_child_tables(float4 *lds) {
+    const uint32_t *src = reinterpret_cast<const uint32_t *>(&kChildTablesDev);
+    uint32_t *dst = reinterpret_cast<uint32_t *>(lds);
+    for (int i = threadIdx.x; i < kTableWords; i += kBlock) dst[i] = src[i];
+    __syncthreads();
+}
+
+/* dynamic LDS of a workgroup: the tables, the stack frames (16-byte words, then 4-byte words), then one CoopLds per wave.
+ * `lds` here is the start of the stack frames. */
 __device__ __forceinline__ CoopLds *coop_area(float4 *lds, int max_depth) {
     char *base = reinterpret_cast<char *>(lds) + (size_t)stack_levels(max_depth) * kBlock * (sizeof(float4) + sizeof(uint32_t));
     return reinterpret_cast<CoopLds *>(base) + (threadIdx.x >> 6);
@@ -277,7 +290,10 @@ template <bool LOG>
 __global__ void __launch_bounds__(kBlock) trace_kernel(PtSceneDev sc, const float *__restrict__ rays, int64_t n,
                                                        pt_hit *__restrict__ hits, int32_t *__restrict__ log, int log_stride,
                                                        unsigned long long *__restrict__ stats) {
-    extern __shared__ float4 lds_stack[];
+    extern __shared__ float4 lds_raw[];
+    const uint8_t *tabs = reinterpret_cast<const uint8_t *>(lds_raw);
+    float4 *lds_stack = lds_raw + kTableQuads;
+    load_child_tables(lds_raw);
     float4 *stack = lds_stack + threadIdx.x;
     uint32_t *stack1 = reinterpret_cast<uint32_t *>(lds_stack + stack_levels(sc.max_depth) * kBlock) + threadIdx.x;
     CoopLds *coop = coop_area(lds_stack, sc.max_depth);
@@ -321,7 +337,7 @@ __global__ void __launch_bounds__(kBlock) trace_kernel(PtSceneDev sc, const floa
         }
         first = false;
         if (__ballot(L.mode != M_IDLE) == 0ull) break;
-        trace_wave<true, LOG, !LOG, LOG>(sc, L, st, lg, stack, stack1, kBlock, kDoneQuota, kLeafQuota, coop, threadIdx.x & 63);
+        trace_wave<true, LOG, !LOG, LOG>(sc, L, st, lg, stack, stack1, kBlock, kDoneQuota, kLeafQuota, coop, threadIdx.x & 63, tabs);
     }
     if (stats) {
         flush_stat(&stats[0], st.segments);
@@ -398,7 +414,10 @@ __device__ __forceinline__ uint32_t udiv(uint32_t n, const UDiv &d) {
 
 template <bool STATS, int WAVES, bool COOP, bool PREPASS>
 __global__ void __launch_bounds__(kBlock, WAVES) render_kernel(RenderParams P) {
-    extern __shared__ float4 lds_stack[];
+    extern __shared__ float4 lds_raw[];
+    const uint8_t *tabs = reinterpret_cast<const uint8_t *>(lds_raw);
+    float4 *lds_stack = lds_raw + kTableQuads;
+    load_child_tables(lds_raw);
     float4 *stack = lds_stack + threadIdx.x;
     uint32_t *stack1 = reinterpret_cast<uint32_t *>(lds_stack + stack_levels(P.sc.max_depth) * kBlock) + threadIdx.x;
     CoopLds *coop = coop_area(lds_stack, P.sc.max_depth);
@@ -572,7 +591,7 @@ __global__ void __launch_bounds__(kBlock, WAVES) render_kernel(RenderParams P) {
             if (__ballot(!(meta & kDoneBit)) == 0ull) break;      /* every lane is out of work: the grid drains */
             continue;                                /* e.g. lanes that drew an out-of-image slot ask again */
         }
-        trace_wave<STATS, false, COOP, PREPASS>(P.sc, L, st, lg, stack, stack1, kBlock, P.done_quota, P.leaf_quota, coop, lane);
+        trace_wave<STATS, false, COOP, PREPASS>(P.sc, L, st, lg, stack, stack1, kBlock, P.done_quota, P.leaf_quota, coop, lane, tabs);
     }
     if (STATS && P.stats) {
         flush_stat(&P.stats[0], st.segments);
@@ -637,7 +656,7 @@ SlicePlan make_slice_plan(int sample_begin, int sample_end, int n_split) {
 }
 
 static size_t stack_bytes(int max_depth) {
-    return (size_t)stack_levels(max_depth) * kBlock * (sizeof(float4) + sizeof(uint32_t)) + (kBlock / 64) * sizeof(CoopLds);
+    return sizeof(ChildTables) + (size_t)stack_levels(max_depth) * kBlock * (sizeof(float4) + sizeof(uint32_t)) + (kBlock / 64) * sizeof(CoopLds);
 }
 
 int launch_trace(const PtSceneDev &sc, const float *d_rays, int64_t n, pt_hit *d_hits, int32_t *d_log, int log_stride,

@@ -157,6 +157,14 @@ int pt_sample_material(pt_scene *scene, int material, const float *uv, int64_t n
                        float *specular, float *smoothness, float *normal);
 int pt_box_intersects_triangle(const float bmin[3], const float bmax[3], const float v0[3],
                                const float v1[3], const float v2[3], int pad_box, int *overlaps);
+/* pt_child_tables: the two look-up tables of the octree walk's node step as the kernels use them, for tests.
+ * set_out (1024 bytes): the children -- mirrored numbering, bit c = child c -- that the child loop of
+ * Octree::proc_subtree (src/device_geometry_functions.cuh:159-188, with find_first_node :95-110 and next_node
+ * :116-126) steps through, indexed by ten comparisons of the node's interval parameters, most significant bit
+ * first: tMx < te, tMy < te, tMz < te (te = max(t0)), tMx < min(t1y, t1z), t1x < tMy, tMy < t1z,
+ * min(t1x, t1y) < tMz, tMx < tMy, tMx < tMz, tMy < tMz.  mir_out (2048 bytes): [a << 8 | mask] = child mask in the
+ * mirrored numbering of a ray with mirror bits a (:165).  Host only; either pointer may be NULL. */
+int pt_child_tables(uint8_t *set_out, uint8_t *mir_out);
 
 /* ---- render: replaces render_init + device_render (src/renderer.cu:19-51, 233-257).
  * Adds, for every pixel, the radiance samples sample_begin..sample_end-1 into n_split split

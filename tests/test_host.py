@@ -134,3 +134,76 @@ def test_obj_reader_conventions(scenes, tmp_path):
     q.write_text("v 0 0 0\nv 1 0 0\nv 1 1 0\nv 0 1 0\nf 1 2 3 4\n")
     with pytest.raises(ValueError, match="triangles"):
         scenes.load_obj(str(q))
+
+
+def _stepped_child_sets(t0, t1):
+    """The children proc_subtree's loop steps through (src/device_geometry_functions.cuh:159-188), by stepping
+    find_first_node (:95-110) and next_node (:116-126) exactly as written there; float32 throughout."""
+    n = t0.shape[0]
+    tM = (np.float32(0.5) * (t0 + t1)).astype(np.float32)
+    out = np.zeros(n, np.uint32)
+    for k in range(n):
+        a0, aM, a1 = t0[k], tM[k], t1[k]
+        c = 0
+        if a0[0] > a0[1] and a0[0] > a0[2]:
+            c |= 2 if aM[1] < a0[0] else 0
+            c |= 1 if aM[2] < a0[0] else 0
+        elif a0[1] > a0[2]:
+            c |= 4 if aM[0] < a0[1] else 0
+            c |= 1 if aM[2] < a0[1] else 0
+        else:
+            c |= 4 if aM[0] < a0[2] else 0
+            c |= 2 if aM[1] < a0[2] else 0
+        s = 0
+        while c < 8:
+            s |= 1 << c
+            ex = a1[0] if c & 4 else aM[0]
+            ey = a1[1] if c & 2 else aM[1]
+            ez = a1[2] if c & 1 else aM[2]
+            nx = 8 if c & 4 else c | 4
+            ny = 8 if c & 2 else c | 2
+            nz = 8 if c & 1 else c | 1
+            if ex < ey:
+                c = nx if ex < ez else nz
+            else:
+                c = ny if ey < ez else nz
+        out[k] = s
+    return out
+
+
+def test_child_set_table_equals_stepping_the_reference_loop(pt):
+    """The node step reads the set of children to visit from a table keyed by ten comparisons; here the table route,
+    evaluated in numpy with the same comparisons, against the stepped loop on tie-heavy intervals."""
+    L = pt.lib()
+    tab = np.zeros(1024, np.uint8)
+    mir = np.zeros(2048, np.uint8)
+    pt.check(L.pt_child_tables(tab.ctypes.data, mir.ctypes.data))
+    for a in range(8):
+        for m in (0, 1, 0x80, 0xA5, 0x3C, 0xFF, 0x12):
+            assert mir[a << 8 | m] == sum(((m >> (c ^ a)) & 1) << c for c in range(8))
+    rng = np.random.default_rng(7)
+    n = 120000
+    # small integer grids make ties between mid and exit parameters of different axes the common case; a slice of
+    # random reals and degenerate (t0 == t1) axes cover the rest.  Mostly intervals a walk can hold (the ray's spans on
+    # the three axes overlap: max t0 <= min t1), so that sets of two to four children are common
+    t0 = rng.integers(-3, 4, size=(n, 3)).astype(np.float32)
+    w = rng.integers(0, 9, size=(n, 3)).astype(np.float32)
+    t0[: n // 4] = rng.normal(size=(n // 4, 3)).astype(np.float32)
+    w[: n // 4] = (3.0 * np.abs(rng.normal(size=(n // 4, 3)))).astype(np.float32)
+    t1 = (t0 + w).astype(np.float32)
+    keep = (t0.max(axis=1) <= t1.min(axis=1)) | (rng.random(n) < 0.1)
+    t0, t1 = t0[keep], t1[keep]
+    n = t0.shape[0]
+    assert n > 50000
+    tM = (np.float32(0.5) * (t0 + t1)).astype(np.float32)
+    te = t0.max(axis=1)
+    bits = [tM[:, 0] < te, tM[:, 1] < te, tM[:, 2] < te, tM[:, 0] < np.minimum(t1[:, 1], t1[:, 2]), t1[:, 0] < tM[:, 1],
+            tM[:, 1] < t1[:, 2], np.minimum(t1[:, 0], t1[:, 1]) < tM[:, 2], tM[:, 0] < tM[:, 1], tM[:, 0] < tM[:, 2],
+            tM[:, 1] < tM[:, 2]]
+    key = np.zeros(n, np.int64)
+    for b in bits:
+        key = 2 * key + b.astype(np.int64)
+    stepped = _stepped_child_sets(t0, t1)
+    assert np.array_equal(tab[key].astype(np.uint32), stepped)
+    sizes = np.bincount([bin(int(x)).count("1") for x in stepped], minlength=5)
+    assert sizes[2:].min() > 5000 and np.unique(key).size >= 60, (sizes, np.unique(key).size)
