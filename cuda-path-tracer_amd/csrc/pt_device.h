@@ -137,11 +137,12 @@ struct Lane {
  *   bits 24..31  the node's child mask
  * Which children are members follows from ten comparisons between the interval's parameters (pt_child_table.h has
  * the derivation): they are shifted into a key through the carry flag and the set is read from a table in LDS, and
- * so is the node's child mask in the ray's mirrored numbering (`tabs`: ChildTables at the start of the workgroup's LDS).
+ * so is the node's child mask in the ray's mirrored numbering (ChildTables at LDS address 0 of the workgroup: a kernel that
+ * walks octrees copies them there first).
  */
 template <bool STATS>
 __device__ __forceinline__ uint32_t child_list(float t0x, float t0y, float t0z, float t1x, float t1y, float t1z, uint32_t nm,
-                                               int a, const uint8_t *tabs) {
+                                               int a) {
     const float tMx = 0.5f * (t0x + t1x), tMy = 0.5f * (t0y + t1y), tMz = 0.5f * (t0z + t1z);
     /* find_first_node (dgf:95-110): the entry plane is the one with the largest t0, and every OTHER axis whose mid plane
      * lies before the entry point te starts with its bit set.  The entry axis needs no special case: its own mid
@@ -178,7 +179,11 @@ __device__ __forceinline__ uint32_t child_list(float t0x, float t0y, float t0z, 
         : [k] "+v"(key), [myz] "=&v"(myz), [mxy] "=&v"(mxy)
         : [tMx] "v"(tMx), [tMy] "v"(tMy), [tMz] "v"(tMz), [te] "v"(te), [t1x] "v"(t1x), [t1y] "v"(t1y), [t1z] "v"(t1z)
         : "vcc");
-    const uint32_t set = tabs[key];
+    /* (the table reads in assembly, addressed from LDS address 0 where the kernels put the tables: through the pointer each
+     * read carries an addition of the LDS segment's link-time base, which is zero.  The wait after the second read covers
+     * both: LDS returns reads in order) */
+    uint32_t set;
+    asm volatile("ds_read_u8 %0, %1" : "=v"(set) : "v"(key));
     /* dgf:142, (ex < 0 || ey < 0 || ey < 0): y twice, never z.  The parameters are products of finite differences and
      * clamped reciprocals, never NaN, so "negative" is "bit pattern above -0.0".  A member's ex is the node's t1x when
      * its x bit is set, and the node would not have been entered with a negative t1x (the same test, one level up, or
@@ -189,7 +194,9 @@ __device__ __forceinline__ uint32_t child_list(float t0x, float t0y, float t0z, 
      * from pulling uses of the record, and with them the wait for the fetch, up into the comparisons */
     __builtin_amdgcn_sched_barrier(0);
     asm volatile("" : "+v"(nm), "+v"(key));
-    const uint32_t members = set & (uint32_t)tabs[kChildSetEntries + (((uint32_t)a << 8) | nm)];
+    uint32_t mir;
+    asm volatile("ds_read_u8 %0, %1 offset:%2\n\ts_waitcnt lgkmcnt(0)" : "=v"(mir) : "v"(((uint32_t)a << 8) | nm), "n"(kChildSetEntries));
+    const uint32_t members = set & mir;
     uint32_t list = (nm << 24) | (members & ~rej);
     if (STATS) list |= (members & rej) << 8;
     return list;
@@ -240,7 +247,7 @@ __device__ __forceinline__ void lane_start_ray(Lane &L, V3 o, V3 d) {
  */
 /* (the block proper, on a view E of the entity's record: the record itself, or a copy of its rows in registers) */
 template <bool STATS, bool PREPASS, typename E>
-__device__ __forceinline__ void entity_visit(const PtSceneDev &sc, Lane &L, Stats &st, const E &e, const PtEntity *ep, bool masked, const uint8_t *tabs) {
+__device__ __forceinline__ void entity_visit(const PtSceneDev &sc, Lane &L, Stats &st, const E &e, const PtEntity *ep, bool masked) {
     const int32_t ei = L.ent;
     L.ent = ei + 1;                       /* default: move on to the next entity, or finish */
     L.mode = next_entity_mode<PREPASS>(sc, L);
@@ -290,12 +297,12 @@ __device__ __forceinline__ void entity_visit(const PtSceneDev &sc, Lane &L, Stat
     L.t0x = t0x; L.t0y = t0y; L.t0z = t0z; L.t1x = t1x; L.t1y = t1y; L.t1z = t1z;
     L.nb = e.root_a;                      /* the root's node record, copied into the entity's */
     L.a = a; L.path = 1u; L.framed = 0u; L.rem = e.octree_depth - 1;
-    L.todo = child_list<STATS>(t0x, t0y, t0z, t1x, t1y, t1z, e.root_b, a, tabs);
+    L.todo = child_list<STATS>(t0x, t0y, t0z, t1x, t1y, t1z, e.root_b, a);
     L.mode = M_NODE;
 }
 
 template <bool STATS, bool PREPASS, bool TOGETHER>
-__device__ __forceinline__ void entity_block(const PtSceneDev &sc, Lane &L, Stats &st, const uint8_t *tabs) {
+__device__ __forceinline__ void entity_block(const PtSceneDev &sc, Lane &L, Stats &st) {
     const bool masked = PREPASS && uses_entity_mask(sc);
     if (masked) {
         const uint32_t left = L.emask >> L.ent;
@@ -307,7 +314,7 @@ __device__ __forceinline__ void entity_block(const PtSceneDev &sc, Lane &L, Stat
      * own, four in a row.  Pays for scenes of one large mesh (+2 % with 871 k triangles); scenes of many small meshes lose by
      * it (box scene -6 %: most trips end at the box test).  (A sphere's centre and radius are fetched in its branch.) */
     const PtEntity *ep = &sc.entities[L.ent];
-    if (!TOGETHER) { entity_visit<STATS, PREPASS>(sc, L, st, *ep, ep, masked, tabs); return; }
+    if (!TOGETHER) { entity_visit<STATS, PREPASS>(sc, L, st, *ep, ep, masked); return; }
     struct { int32_t shape, material, octree_depth; uint32_t root_node; float aabb_min[3]; uint32_t tri_first; float aabb_max[3]; uint32_t n_tris;
              float region_min[3]; uint32_t shade_base; float region_max[3]; int32_t has_uvs; uint32_t root_a, root_b; } e;
     {
@@ -325,7 +332,7 @@ __device__ __forceinline__ void entity_block(const PtSceneDev &sc, Lane &L, Stat
         e.region_max[0] = r4.x; e.region_max[1] = r4.y; e.region_max[2] = r4.z; e.has_uvs = __float_as_int(r4.w);
         e.root_a = (uint32_t)r6.y; e.root_b = (uint32_t)r6.z;
     }
-    entity_visit<STATS, PREPASS>(sc, L, st, e, ep, masked, tabs);
+    entity_visit<STATS, PREPASS>(sc, L, st, e, ep, masked);
 }
 
 template <bool STATS>
@@ -371,7 +378,7 @@ __device__ __forceinline__ void entity_prepass(const PtSceneDev &sc, Lane &L, St
  * on return: it then returns again in its next trip.)
  */
 template <bool STATS, bool PREPASS>
-__device__ __forceinline__ void node_block(const PtSceneDev &sc, Lane &L, Stats &st, float4 *stack, uint32_t *stack1, int stride, const uint8_t *tabs) {
+__device__ __forceinline__ void node_block(const PtSceneDev &sc, Lane &L, Stats &st, float4 *stack, uint32_t *stack1, int stride) {
     if ((L.todo & 0xFFu) == 0u) {
         if (STATS) st.node_visits += __popc((L.todo >> 8) & 0xFFu);
         const uint32_t above = L.framed >> L.rem;              /* bit 0: the parent's slot */
@@ -444,6 +451,7 @@ __device__ __forceinline__ void node_block(const PtSceneDev &sc, Lane &L, Stats 
     uint32_t pick;                                           /* last ? path : ~curr; bits 0..2 are read */
     asm("v_bitop3_b32 %0, %1, %2, %3 bitop3:0xc5" : "=v"(pick) : "v"(last), "v"(L.path), "v"(curr));
     float4 s;
+    uint32_t sel;                                            /* 0 / ~0: the child takes the upper half of the axis */
     asm("v_add_u32_e32 %0, -1, %0" : "+v"(L.rem));               /* in place, like the interval below */
     const uint32_t bit = 1u << L.rem;
     L.framed = (L.framed & ~bit) | (bit & ~last);
@@ -455,24 +463,23 @@ __device__ __forceinline__ void node_block(const PtSceneDev &sc, Lane &L, Stats 
         "v_bitop3_b32 %[sx], %[sx], %[t1x], %[t0x] bitop3:0xca\n\t"
         "v_bitop3_b32 %[sy], %[sy], %[t1y], %[t0y] bitop3:0xca\n\t"
         "v_bitop3_b32 %[sz], %[sz], %[t1z], %[t0z] bitop3:0xca\n\t"
-        "v_cmp_ne_u32_e32 vcc, 0, %[mx]\n\t"
-        "v_cndmask_b32_e32 %[t0x], %[t0x], %[tMx], vcc\n\t"
-        "v_cndmask_b32_e32 %[t1x], %[tMx], %[t1x], vcc\n\t"
-        "v_cmp_ne_u32_e32 vcc, 0, %[my]\n\t"
-        "v_cndmask_b32_e32 %[t0y], %[t0y], %[tMy], vcc\n\t"
-        "v_cndmask_b32_e32 %[t1y], %[tMy], %[t1y], vcc\n\t"
-        "v_cmp_ne_u32_e32 vcc, 0, %[mz]\n\t"
-        "v_cndmask_b32_e32 %[t0z], %[t0z], %[tMz], vcc\n\t"
-        "v_cndmask_b32_e32 %[t1z], %[tMz], %[t1z], vcc"
-        : [sx] "=&v"(s.x), [sy] "=&v"(s.y), [sz] "=&v"(s.z), [t0x] "+v"(L.t0x), [t1x] "+v"(L.t1x), [t0y] "+v"(L.t0y),
+        "v_bfe_i32 %[m], %[curr], 2, 1\n\t"
+        "v_bitop3_b32 %[t0x], %[m], %[tMx], %[t0x] bitop3:0xca\n\t"
+        "v_bitop3_b32 %[t1x], %[m], %[t1x], %[tMx] bitop3:0xca\n\t"
+        "v_bfe_i32 %[m], %[curr], 1, 1\n\t"
+        "v_bitop3_b32 %[t0y], %[m], %[tMy], %[t0y] bitop3:0xca\n\t"
+        "v_bitop3_b32 %[t1y], %[m], %[t1y], %[tMy] bitop3:0xca\n\t"
+        "v_bfe_i32 %[m], %[curr], 0, 1\n\t"
+        "v_bitop3_b32 %[t0z], %[m], %[tMz], %[t0z] bitop3:0xca\n\t"
+        "v_bitop3_b32 %[t1z], %[m], %[t1z], %[tMz] bitop3:0xca"
+        : [sx] "=&v"(s.x), [sy] "=&v"(s.y), [sz] "=&v"(s.z), [m] "=&v"(sel), [t0x] "+v"(L.t0x), [t1x] "+v"(L.t1x), [t0y] "+v"(L.t0y),
           [t1y] "+v"(L.t1y), [t0z] "+v"(L.t0z), [t1z] "+v"(L.t1z)
-        : [pick] "v"(pick), [mx] "v"(curr & 4), [my] "v"(curr & 2), [mz] "v"(curr & 1), [tMx] "v"(tMx), [tMy] "v"(tMy), [tMz] "v"(tMz)
-        : "vcc");
+        : [pick] "v"(pick), [curr] "v"(curr), [tMx] "v"(tMx), [tMy] "v"(tMy), [tMz] "v"(tMz));
     s.w = __uint_as_float(L.nb);
     stack[L.rem * stride] = s;
     stack1[L.rem * stride] = L.todo;
     asm("v_bitop3_b32 %0, %1, %0, %2 bitop3:0xca" : "+v"(L.path) : "v"(last), "v"((L.path << 3) | (uint32_t)curr));   /* last ? path : path.curr */
-    L.todo = child_list<STATS>(L.t0x, L.t0y, L.t0z, L.t1x, L.t1y, L.t1z, rec.b, L.a, tabs);
+    L.todo = child_list<STATS>(L.t0x, L.t0y, L.t0z, L.t1x, L.t1y, L.t1z, rec.b, L.a);
     asm volatile("v_mov_b32_e32 %0, %1" : "+v"(L.nb) : "v"(rec.a));     /* after the list: the record is used as late as possible */
 }
 
@@ -767,7 +774,7 @@ __device__ __forceinline__ int count_lanes(bool p) {
 #endif
 template <bool STATS, bool LOG, bool COOP, bool PREPASS>
 __device__ __forceinline__ void trace_wave(const PtSceneDev &sc, Lane &L, Stats &st, TriLog &lg, float4 *stack, uint32_t *stack1,
-                                           int stride, int done_quota, int leaf_quota, CoopLds *coop, int lane, const uint8_t *tabs) {
+                                           int stride, int done_quota, int leaf_quota, CoopLds *coop, int lane) {
     static_assert(!(LOG && COOP), "the cooperative leaf phase keeps no test log");
     static_assert(!(PREPASS && COOP), "the entity pre-pass belongs to the builds for small scenes");
     for (;;) {
@@ -786,7 +793,7 @@ __device__ __forceinline__ void trace_wave(const PtSceneDev &sc, Lane &L, Stats 
         const int which = (n_ent >= n_node && n_ent >= n_leaf) ? 0 : (!leaf_first ? 1 : 2);
         if (which == 0) {
             if (STATS) st.ent_trips++;
-            if (L.mode == M_ENTITY) { if (STATS) st.ent_lanes++; entity_block<STATS, PREPASS, COOP>(sc, L, st, tabs); }
+            if (L.mode == M_ENTITY) { if (STATS) st.ent_lanes++; entity_block<STATS, PREPASS, COOP>(sc, L, st); }
         }
         if (which == 1) {
             int trips = 0;
@@ -795,7 +802,7 @@ __device__ __forceinline__ void trace_wave(const PtSceneDev &sc, Lane &L, Stats 
 #pragma unroll
                 for (int u = 0; u < PT_NODE_GROUP; u++) {
                     if (STATS) st.node_trips++;
-                    if (L.mode == M_NODE) { if (STATS) st.node_lanes++; node_block<STATS, PREPASS>(sc, L, st, stack, stack1, stride, tabs); }
+                    if (L.mode == M_NODE) { if (STATS) st.node_lanes++; node_block<STATS, PREPASS>(sc, L, st, stack, stack1, stride); }
                 }
             } while ((trips += PT_NODE_GROUP) < PT_TRIPS && PT_KEEP_NODE * __popcll(__ballot(L.mode == M_NODE)) >= n_node &&
                      !(COOP && __popcll(__ballot(L.mode == M_LEAF)) >= leaf_quota));

@@ -33,6 +33,8 @@ static constexpr int kTableWords = (int)(sizeof(ChildTables) / 4), kTableQuads =
 static_assert(sizeof(ChildTables) % 16 == 0, "the stack frames behind the tables are 16-byte words");
 
 __device__ __forceinline__ void load_child_tables(float4 *lds) {
+    /* the node step addresses the tables from LDS address 0: the kernels here have no static LDS in front of the dynamic segment */
+    if ((uint32_t)(uintptr_t)lds != 0u) __builtin_trap();
     const uint32_t *src = reinterpret_cast<const uint32_t *>(&kChildTablesDev);
     uint32_t *dst = reinterpret_cast<uint32_t *>(lds);
     for (int i = threadIdx.x; i < kTableWords; i += kBlock) dst[i] = src[i];
@@ -291,7 +293,6 @@ __global__ void __launch_bounds__(kBlock) trace_kernel(PtSceneDev sc, const floa
                                                        pt_hit *__restrict__ hits, int32_t *__restrict__ log, int log_stride,
                                                        unsigned long long *__restrict__ stats) {
     extern __shared__ float4 lds_raw[];
-    const uint8_t *tabs = reinterpret_cast<const uint8_t *>(lds_raw);
     float4 *lds_stack = lds_raw + kTableQuads;
     load_child_tables(lds_raw);
     float4 *stack = lds_stack + threadIdx.x;
@@ -337,7 +338,7 @@ __global__ void __launch_bounds__(kBlock) trace_kernel(PtSceneDev sc, const floa
         }
         first = false;
         if (__ballot(L.mode != M_IDLE) == 0ull) break;
-        trace_wave<true, LOG, !LOG, LOG>(sc, L, st, lg, stack, stack1, kBlock, kDoneQuota, kLeafQuota, coop, threadIdx.x & 63, tabs);
+        trace_wave<true, LOG, !LOG, LOG>(sc, L, st, lg, stack, stack1, kBlock, kDoneQuota, kLeafQuota, coop, threadIdx.x & 63);
     }
     if (stats) {
         flush_stat(&stats[0], st.segments);
@@ -415,7 +416,6 @@ __device__ __forceinline__ uint32_t udiv(uint32_t n, const UDiv &d) {
 template <bool STATS, int WAVES, bool COOP, bool PREPASS>
 __global__ void __launch_bounds__(kBlock, WAVES) render_kernel(RenderParams P) {
     extern __shared__ float4 lds_raw[];
-    const uint8_t *tabs = reinterpret_cast<const uint8_t *>(lds_raw);
     float4 *lds_stack = lds_raw + kTableQuads;
     load_child_tables(lds_raw);
     float4 *stack = lds_stack + threadIdx.x;
@@ -591,7 +591,7 @@ __global__ void __launch_bounds__(kBlock, WAVES) render_kernel(RenderParams P) {
             if (__ballot(!(meta & kDoneBit)) == 0ull) break;      /* every lane is out of work: the grid drains */
             continue;                                /* e.g. lanes that drew an out-of-image slot ask again */
         }
-        trace_wave<STATS, false, COOP, PREPASS>(P.sc, L, st, lg, stack, stack1, kBlock, P.done_quota, P.leaf_quota, coop, lane, tabs);
+        trace_wave<STATS, false, COOP, PREPASS>(P.sc, L, st, lg, stack, stack1, kBlock, P.done_quota, P.leaf_quota, coop, lane);
     }
     if (STATS && P.stats) {
         flush_stat(&P.stats[0], st.segments);
