@@ -432,6 +432,10 @@ int pt_scene_commit(pt_scene *scene) {
     }
     if (nodes.size() >= (1ull << 29) || recs.size() * sizeof(PtTriPair) >= (1ull << 32)) PT_FAIL("pt_scene_commit: scene too large (limits: 4 GiB of triangle pairs, 2^29 octree nodes)");
 
+    /* PTAMD_PLAIN_MAPS=1 keeps textures and the environment map in their row-major upload layouts (the code paths of maps
+     * with different resolutions and of nearest-texel environment look-ups): for A/B measurements and tests */
+    const char *plain_env = getenv("PTAMD_PLAIN_MAPS");
+    const bool plain_layouts = plain_env && plain_env[0] == '1';
     std::vector<PtMaterial> mats(scene->materials.size());
     for (size_t i = 0; i < scene->materials.size(); i++) {
         const MaterialHost &h = scene->materials[i];
@@ -444,13 +448,55 @@ int pt_scene_commit(pt_scene *scene) {
         m.smooth_shading = h.d.smooth_shading ? 1 : 0;
         const int w[4] = {h.d.albedo_w, h.d.specular_w, h.d.normal_w, h.d.smoothness_w};
         const int hh[4] = {h.d.albedo_h, h.d.specular_h, h.d.normal_h, h.d.smoothness_h};
+        /* maps of one resolution go into texel records (PtMaterial::packed): one look-up per hit instead of one per map */
+        int first = -1;
+        bool same = true;
         for (int k = 0; k < 4; k++) {
             if (h.maps[k].empty()) continue;
-            const uint8_t *d = nullptr;
-            if (upload_vec(scene, h.maps[k], &d, &scene->bytes_tex)) return 1;
-            m.map[k] = d;
-            m.map_w[k] = w[k];
-            m.map_h[k] = hh[k];
+            if (first < 0) first = k;
+            same = same && w[k] == w[first] && hh[k] == hh[first];
+        }
+        const uint32_t shift = h.maps[PT_MAP_SPECULAR].empty() ? 3u : 4u;
+        const uint64_t tiles_x = first >= 0 ? ((uint64_t)w[first] + 3) / 4 : 0, tiles_y = first >= 0 ? ((uint64_t)hh[first] + 3) / 4 : 0;
+        const uint64_t n_records = tiles_x * tiles_y * 16;
+        if (first >= 0 && same && !plain_layouts && (n_records << shift) < (1ull << 32)) {
+            const uint8_t *d_maps[4] = {nullptr, nullptr, nullptr, nullptr};
+            std::vector<void *> tmp;
+            int rc = 0;
+            void *d_packed = nullptr;
+            do {
+                for (int k = 0; k < 4 && !rc; k++) {
+                    if (h.maps[k].empty()) continue;
+                    void *d = nullptr;
+                    if (hipMalloc(&d, h.maps[k].size()) != hipSuccess) { rc = hip_fail(hipErrorOutOfMemory, "hipMalloc map", __FILE__, __LINE__); break; }
+                    tmp.push_back(d);
+                    if (hipMemcpy(d, h.maps[k].data(), h.maps[k].size(), hipMemcpyHostToDevice) != hipSuccess) { rc = 1; set_error("pt_scene_commit: map upload failed"); break; }
+                    d_maps[k] = static_cast<const uint8_t *>(d);
+                    m.packed_mask |= 1u << k;
+                }
+                if (rc) break;
+                if (hipMalloc(&d_packed, (size_t)(n_records << shift)) != hipSuccess) { rc = hip_fail(hipErrorOutOfMemory, "hipMalloc texel records", __FILE__, __LINE__); break; }
+                scene->allocs.push_back(d_packed);
+                rc = launch_pack_maps(d_maps, w[first], hh[first], (uint32_t)tiles_x, (uint32_t)n_records, shift, static_cast<uint8_t *>(d_packed), nullptr);
+                if (!rc && hipStreamSynchronize(nullptr) != hipSuccess) { rc = 1; set_error("pt_scene_commit: packing the maps failed"); }
+            } while (0);
+            for (void *d : tmp) (void)hipFree(d);
+            if (rc) return 1;
+            m.packed = static_cast<const uint8_t *>(d_packed);
+            m.packed_tiles_x = (uint32_t)tiles_x;
+            m.packed_shift = shift;
+            m.packed_w_f = (float)w[first]; m.packed_h_f = (float)hh[first];
+            m.packed_xmax_f = (float)(w[first] - 1); m.packed_ymax_f = (float)(hh[first] - 1);
+            scene->bytes_tex += n_records << shift;
+        } else {
+            for (int k = 0; k < 4; k++) {
+                if (h.maps[k].empty()) continue;
+                const uint8_t *d = nullptr;
+                if (upload_vec(scene, h.maps[k], &d, &scene->bytes_tex)) return 1;
+                m.map[k] = d;
+                m.map_w[k] = w[k];
+                m.map_h[k] = hh[k];
+            }
         }
         mats[i] = m;
     }
@@ -462,7 +508,28 @@ int pt_scene_commit(pt_scene *scene) {
     if (upload_vec(scene, recs, &d.tris, &scene->bytes_tris)) return 1;
     if (upload_vec(scene, shade, &d.shade, &scene->bytes_shade)) return 1;
     if (upload_vec(scene, mats, &d.materials, nullptr)) return 1;
-    if (scene->has_hdri && upload_vec(scene, scene->hdri, &d.hdri, &scene->bytes_hdri)) return 1;
+    if (scene->has_hdri) {
+        const uint64_t n_texels = (uint64_t)scene->hdri_w * (uint64_t)scene->hdri_h;
+        if (scene->hdri_smooth && !plain_layouts && n_texels * 64 < (1ull << 32)) {
+            /* bilinear look-ups read one 64-byte record of four texels (PtSceneDev::hdri_quads), expanded on the device */
+            void *d_img = nullptr, *d_quads = nullptr;
+            int rc = 0;
+            do {
+                if (hipMalloc(&d_img, scene->hdri.size() * sizeof(float)) != hipSuccess) { rc = hip_fail(hipErrorOutOfMemory, "hipMalloc hdri", __FILE__, __LINE__); break; }
+                if (hipMemcpy(d_img, scene->hdri.data(), scene->hdri.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) { rc = 1; set_error("pt_scene_commit: environment map upload failed"); break; }
+                if (hipMalloc(&d_quads, (size_t)(n_texels * 64)) != hipSuccess) { rc = hip_fail(hipErrorOutOfMemory, "hipMalloc hdri records", __FILE__, __LINE__); break; }
+                scene->allocs.push_back(d_quads);
+                rc = launch_hdri_quads(static_cast<const float *>(d_img), scene->hdri_w, scene->hdri_h, static_cast<float *>(d_quads), nullptr);
+                if (!rc && hipStreamSynchronize(nullptr) != hipSuccess) { rc = 1; set_error("pt_scene_commit: expanding the environment map failed"); }
+            } while (0);
+            if (d_img) (void)hipFree(d_img);
+            if (rc) return 1;
+            d.hdri_quads = static_cast<const float *>(d_quads);
+            scene->bytes_hdri += n_texels * 64;
+        } else if (upload_vec(scene, scene->hdri, &d.hdri, &scene->bytes_hdri)) {
+            return 1;
+        }
+    }
     d.n_entities = (int32_t)ents.size();
     d.hdri_w = scene->hdri_w; d.hdri_h = scene->hdri_h;
     d.hdri_w_f = (float)scene->hdri_w; d.hdri_h_f = (float)scene->hdri_h;

@@ -105,6 +105,9 @@ int launch_trace(const PtSceneDev &sc, const float *d_rays, int64_t n, pt_hit *d
                  int log_stride, unsigned long long *d_stats, hipStream_t stream);
 int launch_sample_hdri(const PtSceneDev &sc, const float *d_dirs, int64_t n, float *d_out, hipStream_t stream);
 int launch_sample_material(const PtSceneDev &sc, int material, const float *d_uv, int64_t n, float *d_out, hipStream_t stream);
+/* scene arrays laid out for their access, made on the device at commit (pt_types.h: PtMaterial::packed, PtSceneDev::hdri_quads) */
+int launch_pack_maps(const uint8_t *const d_maps[4], int w, int h, uint32_t tiles_x, uint32_t n_records, uint32_t shift, uint8_t *d_out, hipStream_t stream);
+int launch_hdri_quads(const float *d_img, int w, int h, float *d_out, hipStream_t stream);
 int launch_camera_rays(const pt_camera &cam, uint32_t seed, int sample, float *d_rays, hipStream_t stream);
 /* heavy: the build for scenes dominated by octree traversal (more waves per SIMD, fewer registers) */
 int render_workgroups_per_cu(int max_depth, bool heavy);

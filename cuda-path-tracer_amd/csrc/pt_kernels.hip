@@ -108,6 +108,50 @@ __device__ __forceinline__ float tex_gray(const uint8_t *data, int w, int h, flo
     return (float)data[(size_t)y * (size_t)w + (size_t)x] * (1.0f / 255.0f);
 }
 
+/* The four material samples of one hit (src/material.cuh:21-44: sample_normal, sample_albedo, sample_smoothness,
+ * sample_specular; constants where a map is not set).  Maps of one resolution are read from the material's texel
+ * records (PtMaterial::packed): one texel index and one 8- or 16-byte load for all of them. */
+struct MatSample { V3 albedo, specular, ts_normal; float smoothness; };
+template <bool STATS>
+__device__ __forceinline__ void sample_material(const PtMaterial &m, float u, float v, MatSample &o, Stats &st) {
+    PT_SHADING_FP
+    const float k = 1.0f / 255.0f;
+    o.ts_normal = mk(0.f, 0.f, 1.f);
+    o.albedo = mk(m.albedo[0], m.albedo[1], m.albedo[2]);
+    o.smoothness = m.smoothness;
+    o.specular = mk(m.specular[0], m.specular[1], m.specular[2]);
+    if (m.packed) {
+        uint32_t x = (uint32_t)(int)__builtin_amdgcn_fmed3f(u * m.packed_w_f, 0.0f, m.packed_xmax_f);           /* to_index */
+        uint32_t y = (uint32_t)(int)__builtin_amdgcn_fmed3f((1.0f - v) * m.packed_h_f, 0.0f, m.packed_ymax_f);
+#ifdef PT_PROBE_TEXEL0
+        x = 0; y = 0;
+#endif
+        const uint32_t rec = (((y >> 2) * m.packed_tiles_x + (x >> 2)) << 4) | ((y & 3u) << 2) | (x & 3u);
+        const char *p = reinterpret_cast<const char *>(m.packed) + (rec << m.packed_shift);      /* 32-bit byte offset (checked when packed) */
+        const uint2 w = *reinterpret_cast<const uint2 *>(p);
+        if (STATS) st.tex_fetches += (uint32_t)__popc(m.packed_mask);
+        if (m.packed_mask & (1u << PT_MAP_NORMAL)) {
+            const V3 c = mk((float)(w.x >> 24) * k, (float)(w.y & 0xFFu) * k, (float)((w.y >> 8) & 0xFFu) * k);
+            o.ts_normal = fast_normalized(mk(2.0f * c.x - 1.0f, 2.0f * c.y - 1.0f, 2.0f * c.z - 1.0f));
+        }
+        if (m.packed_mask & (1u << PT_MAP_ALBEDO)) o.albedo = mk((float)(w.x & 0xFFu) * k, (float)((w.x >> 8) & 0xFFu) * k, (float)((w.x >> 16) & 0xFFu) * k);
+        if (m.packed_mask & (1u << PT_MAP_SMOOTHNESS)) o.smoothness = (float)((w.y >> 16) & 0xFFu) * k;
+        if (m.packed_mask & (1u << PT_MAP_SPECULAR)) {
+            const uint32_t w2 = *reinterpret_cast<const uint32_t *>(p + 8);
+            o.specular = mk((float)(w2 & 0xFFu) * k, (float)((w2 >> 8) & 0xFFu) * k, (float)((w2 >> 16) & 0xFFu) * k);
+        }
+        return;
+    }
+    if (m.map[PT_MAP_NORMAL]) {
+        if (STATS) st.tex_fetches++;
+        const V3 c = tex_rgb(m.map[2], m.map_w[2], m.map_h[2], u, v);
+        o.ts_normal = fast_normalized(mk(2.0f * c.x - 1.0f, 2.0f * c.y - 1.0f, 2.0f * c.z - 1.0f));
+    }
+    if (m.map[PT_MAP_ALBEDO]) { if (STATS) st.tex_fetches++; o.albedo = tex_rgb(m.map[0], m.map_w[0], m.map_h[0], u, v); }
+    if (m.map[PT_MAP_SMOOTHNESS]) { if (STATS) st.tex_fetches++; o.smoothness = tex_gray(m.map[3], m.map_w[3], m.map_h[3], u, v); }
+    if (m.map[PT_MAP_SPECULAR]) { if (STATS) st.tex_fetches++; o.specular = tex_rgb(m.map[1], m.map_w[1], m.map_h[1], u, v); }
+}
+
 /* src/scene.cuh:36-82 */
 template <bool STATS>
 __device__ __forceinline__ V3 sample_hdri(const PtSceneDev &sc, V3 v, Stats &st) {
@@ -137,12 +181,26 @@ __device__ __forceinline__ V3 sample_hdri(const PtSceneDev &sc, V3 v, Stats &st)
         const float *p = PT_HDRI_TEXEL(x_l, y_l);
         res = mk(p[0], p[1], p[2]);
     } else {
-        /* (x_l + 1) % W with x_l in [0, W): a wrap, not a division */
-        const uint32_t x_r = x_l + 1u == W ? 0u : x_l + 1u, y_r = y_l + 1u == H ? 0u : y_l + 1u;
         const float xw = fminf(fmaxf(x_c * Wf - (float)(int)x_l, 0.0f), 1.0f);
         const float yw = fminf(fmaxf(y_c * Hf - (float)(int)y_l, 0.0f), 1.0f);
-        const float *ul = PT_HDRI_TEXEL(x_l, y_l), *ur = PT_HDRI_TEXEL(x_r, y_l);
-        const float *ll = PT_HDRI_TEXEL(x_l, y_r), *lr = PT_HDRI_TEXEL(x_r, y_r);
+        float ul[3], ur[3], ll[3], lr[3];
+        if (sc.hdri_quads) {
+            /* the four texels of this look-up, side by side in one 64-byte record */
+#ifdef PT_PROBE_HDRI0
+            const uint32_t rec = 0u;
+#else
+            const uint32_t rec = y_l * W + x_l;
+#endif
+            const float4 *q = reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(sc.hdri_quads) + (rec << 6));
+            const float4 q0 = q[0], q1 = q[1], q2 = q[2];
+            ul[0] = q0.x; ul[1] = q0.y; ul[2] = q0.z; ur[0] = q0.w; ur[1] = q1.x; ur[2] = q1.y;
+            ll[0] = q1.z; ll[1] = q1.w; ll[2] = q2.x; lr[0] = q2.y; lr[1] = q2.z; lr[2] = q2.w;
+        } else {
+            /* (x_l + 1) % W with x_l in [0, W): a wrap, not a division */
+            const uint32_t x_r = x_l + 1u == W ? 0u : x_l + 1u, y_r = y_l + 1u == H ? 0u : y_l + 1u;
+            const float *a = PT_HDRI_TEXEL(x_l, y_l), *b = PT_HDRI_TEXEL(x_r, y_l), *c = PT_HDRI_TEXEL(x_l, y_r), *d = PT_HDRI_TEXEL(x_r, y_r);
+            for (int k = 0; k < 3; k++) { ul[k] = a[k]; ur[k] = b[k]; ll[k] = c[k]; lr[k] = d[k]; }
+        }
         /* bilerp of src/math_util.cuh:20-24: lerp(lerp(ul,ll,v), lerp(ur,lr,v), u) */
         float o[3];
         for (int k = 0; k < 3; k++) {
@@ -217,18 +275,11 @@ __device__ __forceinline__ void shade_hit(const PtSceneDev &sc, const Best &best
                                           V3 &o, V3 &d, V3 &atten, V3 &result, Stats &st) {
     PT_SHADING_FP
     const PtMaterial &m = sc.materials[sc.entities[best.entity].material];
-    V3 ts_normal = mk(0.f, 0.f, 1.f);
-    if (m.map[2]) {
-        if (STATS) st.tex_fetches++;
-        const V3 c = tex_rgb(m.map[2], m.map_w[2], m.map_h[2], sf.u, sf.v);
-        ts_normal = fast_normalized(mk(2.0f * c.x - 1.0f, 2.0f * c.y - 1.0f, 2.0f * c.z - 1.0f));
-    }
-    V3 albedo = mk(m.albedo[0], m.albedo[1], m.albedo[2]);
-    if (m.map[0]) { if (STATS) st.tex_fetches++; albedo = tex_rgb(m.map[0], m.map_w[0], m.map_h[0], sf.u, sf.v); }
-    float smoothness = m.smoothness;
-    if (m.map[3]) { if (STATS) st.tex_fetches++; smoothness = tex_gray(m.map[3], m.map_w[3], m.map_h[3], sf.u, sf.v); }
-    V3 specular = mk(m.specular[0], m.specular[1], m.specular[2]);
-    if (m.map[1]) { if (STATS) st.tex_fetches++; specular = tex_rgb(m.map[1], m.map_w[1], m.map_h[1], sf.u, sf.v); }
+    MatSample ms;
+    sample_material<STATS>(m, sf.u, sf.v, ms, st);
+    const V3 ts_normal = ms.ts_normal, specular = ms.specular;
+    V3 albedo = ms.albedo;
+    const float smoothness = ms.smoothness;
     const float emission = m.emission;
     const V3 normal = to_world(ts_normal, tangent_space(sf.normal));
 
@@ -379,22 +430,70 @@ __global__ void __launch_bounds__(kBlock) sample_material_kernel(PtSceneDev sc, 
     if (i >= n) return;
     const PtMaterial &m = sc.materials[material];
     const float u = uv[2 * i], v = uv[2 * i + 1];
-    V3 ts_normal = mk(0.f, 0.f, 1.f);
-    if (m.map[2]) {
-        const V3 c = tex_rgb(m.map[2], m.map_w[2], m.map_h[2], u, v);
-        ts_normal = fast_normalized(mk(2.0f * c.x - 1.0f, 2.0f * c.y - 1.0f, 2.0f * c.z - 1.0f));
-    }
-    V3 albedo = mk(m.albedo[0], m.albedo[1], m.albedo[2]);
-    if (m.map[0]) albedo = tex_rgb(m.map[0], m.map_w[0], m.map_h[0], u, v);
-    float smoothness = m.smoothness;
-    if (m.map[3]) smoothness = tex_gray(m.map[3], m.map_w[3], m.map_h[3], u, v);
-    V3 specular = mk(m.specular[0], m.specular[1], m.specular[2]);
-    if (m.map[1]) specular = tex_rgb(m.map[1], m.map_w[1], m.map_h[1], u, v);
+    MatSample ms;
+    Stats st;
+    sample_material<false>(m, u, v, ms, st);
+    const V3 albedo = ms.albedo, specular = ms.specular, ts_normal = ms.ts_normal;
+    const float smoothness = ms.smoothness;
     float *o = out + 10 * i;
     o[0] = albedo.x; o[1] = albedo.y; o[2] = albedo.z;
     o[3] = specular.x; o[4] = specular.y; o[5] = specular.z;
     o[6] = smoothness;
     o[7] = ts_normal.x; o[8] = ts_normal.y; o[9] = ts_normal.z;
+}
+
+/* ------------------------------------------------------------------ scene arrays laid out for their access (run once, at commit) */
+/* texel records of a material (PtMaterial::packed) from its separate row-major maps; one thread per record, padding included */
+__global__ void __launch_bounds__(kBlock) pack_maps_kernel(const uint8_t *__restrict__ albedo, const uint8_t *__restrict__ specular,
+                                                           const uint8_t *__restrict__ normal, const uint8_t *__restrict__ smooth, int w, int h,
+                                                           uint32_t tiles_x, uint32_t n_records, uint32_t shift, uint8_t *__restrict__ out) {
+    const uint32_t r = blockIdx.x * kBlock + threadIdx.x;
+    if (r >= n_records) return;
+    const uint32_t tile = r >> 4, ty = tile / tiles_x, tx = tile - ty * tiles_x;
+    const int x = (int)(tx * 4u + (r & 3u)), y = (int)(ty * 4u + ((r >> 2) & 3u));
+    uint32_t w0 = 0u, w1 = 0u, w2 = 0u;
+    if (x < w && y < h) {
+        const size_t t = (size_t)y * (size_t)w + (size_t)x;
+        if (albedo) w0 |= (uint32_t)albedo[3 * t] | ((uint32_t)albedo[3 * t + 1] << 8) | ((uint32_t)albedo[3 * t + 2] << 16);
+        if (normal) {
+            w0 |= (uint32_t)normal[3 * t] << 24;
+            w1 |= (uint32_t)normal[3 * t + 1] | ((uint32_t)normal[3 * t + 2] << 8);
+        }
+        if (smooth) w1 |= (uint32_t)smooth[t] << 16;
+        if (specular) w2 |= (uint32_t)specular[3 * t] | ((uint32_t)specular[3 * t + 1] << 8) | ((uint32_t)specular[3 * t + 2] << 16);
+    }
+    uint32_t *o = reinterpret_cast<uint32_t *>(out + ((size_t)r << shift));
+    o[0] = w0; o[1] = w1;
+    if (shift == 4u) { o[2] = w2; o[3] = 0u; }
+}
+
+/* the records of bilinear environment look-ups (PtSceneDev::hdri_quads) from the row-major image */
+__global__ void __launch_bounds__(kBlock) hdri_quads_kernel(const float *__restrict__ img, int w, int h, float *__restrict__ out) {
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= (uint32_t)w * (uint32_t)h) return;
+    const uint32_t y = i / (uint32_t)w, x = i - y * (uint32_t)w;
+    const uint32_t xr = x + 1u == (uint32_t)w ? 0u : x + 1u, yr = y + 1u == (uint32_t)h ? 0u : y + 1u;     /* (x + 1) % w, (y + 1) % h: src/scene.cuh:62-65 */
+    const float *a = img + 3 * ((size_t)y * w + x), *b = img + 3 * ((size_t)y * w + xr);
+    const float *c = img + 3 * ((size_t)yr * w + x), *d = img + 3 * ((size_t)yr * w + xr);
+    float4 *o = reinterpret_cast<float4 *>(out + 16 * (size_t)i);
+    o[0] = make_float4(a[0], a[1], a[2], b[0]);
+    o[1] = make_float4(b[1], b[2], c[0], c[1]);
+    o[2] = make_float4(c[2], d[0], d[1], d[2]);
+    o[3] = make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
+int launch_pack_maps(const uint8_t *const d_maps[4], int w, int h, uint32_t tiles_x, uint32_t n_records, uint32_t shift, uint8_t *d_out, hipStream_t stream) {
+    hipLaunchKernelGGL(pack_maps_kernel, dim3((n_records + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, d_maps[PT_MAP_ALBEDO], d_maps[PT_MAP_SPECULAR],
+                       d_maps[PT_MAP_NORMAL], d_maps[PT_MAP_SMOOTHNESS], w, h, tiles_x, n_records, shift, d_out);
+    PT_HIP(hipGetLastError());
+    return 0;
+}
+
+int launch_hdri_quads(const float *d_img, int w, int h, float *d_out, hipStream_t stream) {
+    const uint32_t n = (uint32_t)w * (uint32_t)h;
+    hipLaunchKernelGGL(hdri_quads_kernel, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, d_img, w, h, d_out);
+    PT_HIP(hipGetLastError());
+    return 0;
 }
 
 /* ------------------------------------------------------------------ persistent render kernel */

@@ -62,16 +62,32 @@ struct alignas(16) PtEntity {
     int32_t  pad;
 };
 
+/* Texel records of a material whose maps all have one resolution: the 8-bit texels of the maps side by side, so that
+ * one load serves the three or four look-ups a hit makes at the same (u, v), in tiles of 4 x 4 texels (a tile of
+ * 8-byte records is one 128-byte line: hits that are neighbours on the surface share lines in both directions).
+ *   bytes 0..2 albedo rgb, 3..5 normal rgb, 6 smoothness, 7 unused;  16-byte records (a specular map is set): 8..10
+ *   specular rgb, 11..15 unused.  Bytes of maps that are not set are zero and never read.
+ * record index of texel (x, y) = ((y / 4) * tiles_x + x / 4) * 16 + (y % 4) * 4 + x % 4 */
+#define PT_MAP_ALBEDO 0
+#define PT_MAP_SPECULAR 1
+#define PT_MAP_NORMAL 2
+#define PT_MAP_SMOOTHNESS 3
+
 struct PtMaterial {
     float albedo[3];
     float emission;
     float specular[3];
     float smoothness;
     int32_t smooth_shading;
-    int32_t pad;
-    const uint8_t *map[4];     /* albedo, specular, normal (RGB8), smoothness (G8); null = unset */
+    uint32_t packed_mask;      /* packed != null: bit k = map k is set */
+    const uint8_t *map[4];     /* separate row-major maps (maps of different resolutions): albedo, specular, normal (RGB8), smoothness (G8);
+                                * null = unset, or in `packed` */
     int32_t map_w[4];
     int32_t map_h[4];
+    const uint8_t *packed;     /* texel records of all set maps (see above), or null */
+    uint32_t packed_tiles_x;
+    uint32_t packed_shift;     /* log2 of the record size: 3 or 4 */
+    float packed_w_f, packed_h_f, packed_xmax_f, packed_ymax_f;   /* (float)w, (float)h, (float)(w - 1), (float)(h - 1) */
 };
 
 struct PtSceneDev {
@@ -80,7 +96,10 @@ struct PtSceneDev {
     const PtTriPair  *tris;
     const PtShadeRec *shade;
     const PtMaterial *materials;
-    const float      *hdri;    /* h x w x 3 */
+    const float      *hdri;    /* h x w x 3, row 0 first; null when hdri_quads is set */
+    const float      *hdri_quads;   /* bilinear look-ups: per texel (x, y) one 64-byte record holding the four texels the look-up
+                                     * at that texel blends -- (x, y), (x+1, y), (x, y+1), (x+1, y+1), indices wrapping -- as 12
+                                     * floats + 4 unused: one aligned line fetch per look-up instead of two to four */
     int32_t n_entities;
     int32_t hdri_w, hdri_h;
     float   hdri_w_f, hdri_h_f, hdri_xmax_f, hdri_ymax_f;   /* (float)w, (float)h, (float)(w - 1), (float)(h - 1): made once on the

@@ -123,6 +123,21 @@ def test_both_kernel_builds_give_identical_images(pt, scenes, monkeypatch):
             assert ref[1] == v[1], (depth, k)
 
 
+def test_map_layouts_give_identical_images(pt, scenes, monkeypatch):
+    """Texel records and environment-map records (the default upload layouts) hold the same texels as the row-major
+    maps they are made from (PTAMD_PLAIN_MAPS=1): identical image bits and work counters."""
+    desc = scenes.hcandersen_scene(res=(96, 54), n_tris=6000, tex_res=128, hdri_res=(128, 64))
+    out = {}
+    for plain in ("0", "1"):
+        monkeypatch.setenv("PTAMD_PLAIN_MAPS", plain)
+        g, cam = pt.scene_from_description(desc)
+        out[plain] = pt.render_image(g, cam, 32, seed=5, want_counters=True)
+        g.close()
+    assert out["0"][0].max() > 0 and out["0"][1]["tex_fetches"] > 0 and out["0"][1]["env_lookups"] > 0
+    assert np.array_equal(out["0"][0].view(np.uint32), out["1"][0].view(np.uint32))
+    assert out["0"][1] == out["1"][1]
+
+
 def test_launch_choices_do_not_change_the_image(pt, scenes):
     """Kernel build and quorum only change how a wave schedules its lanes: every combination gives
     the bits of the default launch, work counters included; commit derives the defaults from the scene."""

@@ -67,6 +67,61 @@ def test_sample_material_and_texel_edges(pt, oracle, t0):
     g.close()
 
 
+def test_texel_records_equal_separate_maps_and_oracle(pt, oracle, monkeypatch):
+    """Maps of one resolution are uploaded as texel records (one 8- or 16-byte record per texel, 4x4-texel tiles);
+    PTAMD_PLAIN_MAPS=1 keeps them as separate row-major maps.  Same texels either way: identical bits, and both
+    within 1 ulp of the oracle (byte * (1 / 255) against byte / 255).  Sizes that are not multiples of the tile,
+    every subset of maps, both record sizes."""
+    rng = np.random.default_rng(11)
+    cases = [((8, 4), ("albedo", "specular", "normal", "smoothness")), ((13, 7), ("albedo", "normal", "smoothness")),
+             ((5, 9), ("specular",)), ((64, 32), ("normal",)), ((3, 3), ("smoothness",)), ((31, 17), ("albedo", "specular"))]
+    for (tw, th), names in cases:
+        maps = {k: rng.integers(0, 256, (th, tw) if k == "smoothness" else (th, tw, 3), dtype=np.uint8) for k in names}
+        us = np.concatenate([(np.arange(tw) + 0.5) / tw, [0.0, 1.0, 0.999999, 1e-7]])
+        vs = np.concatenate([(np.arange(th) + 0.5) / th, [0.0, 1.0, 1e-7, 0.999999]])
+        uv = np.stack(np.meshgrid(us, vs, indexing="ij"), axis=-1).reshape(-1, 2).astype(np.float32)
+        got = {}
+        for plain in ("0", "1"):
+            monkeypatch.setenv("PTAMD_PLAIN_MAPS", plain)
+            g = pt.Scene(0)
+            mid = g.add_material((0.8, 0.7, 0.6), (0.2, 0.1, 0.3), 0.0, 0.5, False, maps)
+            g.commit()
+            got[plain] = g.sample_material(mid, uv)
+            tex_bytes = g.device_bytes()["textures"]
+            g.close()
+            if plain == "0":       # records: 16 bytes with a specular map, else 8, whole tiles
+                assert tex_bytes == (-(-tw // 4)) * (-(-th // 4)) * 16 * (16 if "specular" in names else 8), (tw, th, names)
+        for a, b in zip(got["0"], got["1"]):
+            assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), (tw, th, names)
+        c = oracle.OracleScene()
+        om = c.add_material((0.8, 0.7, 0.6), (0.2, 0.1, 0.3), 0.0, 0.5, False)
+        for k, v in maps.items():
+            c.set_map(om, k, v)
+        for a, b, tol in zip(got["0"], c.sample_material(om, uv), (6e-8, 6e-8, 6e-8, 1e-6)):
+            assert np.abs(a - b).max() <= tol, (tw, th, names)
+
+
+def test_environment_records_equal_row_major_image(pt, t0, monkeypatch):
+    """Bilinear environment look-ups read one 64-byte record of four texels; PTAMD_PLAIN_MAPS=1 keeps the row-major
+    image and four texel reads.  Identical bits, wrap column and last row included."""
+    img = t0["hdri_image"]
+    rng = np.random.default_rng(5)
+    dirs = rng.normal(size=(20000, 3)).astype(np.float32)
+    dirs /= np.linalg.norm(dirs, axis=1, keepdims=True)
+    dirs = np.concatenate([dirs, np.array([[0, 1, 0], [0, -1, 0], [1e-9, 0.3, -1], [-1e-9, 0.3, -1], [0, -0.9999, 1]], np.float32)])
+    got = {}
+    for plain in ("0", "1"):
+        monkeypatch.setenv("PTAMD_PLAIN_MAPS", plain)
+        g = pt.Scene(0)
+        g.set_hdri(img, exposure=1.5, contrast=1.0, rot=0.85, smooth=True)
+        g.commit()
+        got[plain] = g.sample_hdri(dirs)
+        hdri_bytes = g.device_bytes()["hdri"]
+        g.close()
+        assert hdri_bytes == img.shape[0] * img.shape[1] * (64 if plain == "0" else 12)
+    assert np.array_equal(got["0"].view(np.uint32), got["1"].view(np.uint32))
+
+
 def _on_device(pt, img, op):
     buf = pt.DeviceBuffer(0, img.nbytes)
     buf.upload(img)
