@@ -41,12 +41,14 @@ B_ENV = 48                   # bilinear HDRI lookup: 4 texels x 12 B
 B_ENTITY = 128               # entity record (112 B, counted as one 128-byte line) per (segment, entity)
 
 
-VALU_PEAK_TFLOPS = 157.3       # fp32 vector peak of one MI355X (256 CUs x 128 lanes x 2 flop x 2.4 GHz)
 N_SIMD = 1024                  # 256 CUs x 4 SIMDs
 NOMINAL_GHZ = 2.4
-# lane-operations per second when every SIMD keeps its vector unit busy with all 64 lanes of each instruction
-# active, at the one-instruction-per-four-cycles rate the PMC busy time is counted in
-LANE_OP_PEAK_T = N_SIMD * 16 * NOMINAL_GHZ / 1e3       # = 39.3 T lane-op/s
+# ONE vector peak: a SIMD retires 32 lanes of one vector instruction per cycle (a wave64 instruction in two cycles), so the
+# chip offers 1024 x 32 x 2.4e9 lane-operations per second; counted as fused multiply-adds that is the 157.3 TFLOP/s
+# fp32 vector peak.  Both fractions of the roofline line are taken against it.
+LANE_OP_PEAK_T = N_SIMD * 32 * NOMINAL_GHZ / 1e3       # = 78.6 T lane-op/s
+VALU_PEAK_TFLOPS = 2 * LANE_OP_PEAK_T                  # = 157.3 TFLOP/s
+PROFILE_DIR = "r3"             # profiles/<dir>/ holds the counter passes this line may quote
 
 
 def launch_ranks(n):
@@ -78,13 +80,13 @@ def stamped_profile(name, workload_name, world):
     if wl != "hcandersen":          # the headline workload's files have the plain names
         name = name.replace(".json", f"_{wl}.json")
     try:
-        with open(os.path.join(REPO, "profiles", "r2", name)) as f:
+        with open(os.path.join(REPO, "profiles", PROFILE_DIR, name)) as f:
             d = json.load(f)
     except (OSError, ValueError):
         return None
     if d.get("workload") != workload_name or not d.get("source_hash") or d.get("source_hash") != ptamd.source_hash():
         return None
-    d["_file"] = "profiles/r2/" + name
+    d["_file"] = f"profiles/{PROFILE_DIR}/" + name
     return d
 
 
@@ -257,20 +259,31 @@ def main():
         # triangle records are in "geometry_and_scratch" together with the reloads of spilled registers
         hbm["fetch_GBps_by_array"] = {k: round(fj[k] / k_s / 1e9, 1) for k in ("textures", "hdri", "geometry_and_scratch")}
         hbm["fetch_by_array_source"] = fj["_file"]
-    # (d) what binds: vector-instruction issue.  frac = (share of the time the SIMDs' vector units are busy) x (mean share
-    # of the 64 lanes active in a vector instruction) = share of the chip's lane slots that do work
+    # (d) what binds: vector-instruction issue.  achieved = lane-operations of one launch (vector instructions x 64 x the mean
+    # share of lanes active in one: separate --pmc passes over this very launch, a property of the work, not of the run) / the
+    # kernel's duration measured live here; peak = every SIMD retiring 32 lanes per cycle at the nominal clock.
     n_mesh = sum(1 for e in desc["entities"] if e["kind"] == "mesh")
     alg_flops = algorithmic_flops(counters, n_mesh)
     tflops = alg_flops / k_s / 1e12 if k_ms > 0 else 0.0
     busy = pj.get("valu_busy") if pj else None
     lanes = pj.get("active_lanes_per_valu_instruction") if pj else None
-    frac = round(min(busy, 1.0) * lanes, 4) if busy is not None and lanes is not None else None
-    roofline = {"bound": "valu-issue", "achieved": round(frac * LANE_OP_PEAK_T, 2) if frac is not None else None,
+    lane_ops = pj.get("valu_lane_ops_per_launch") if pj else None
+    achieved = lane_ops / k_s / 1e12 if lane_ops and k_ms > 0 else None
+    frac = round(achieved / LANE_OP_PEAK_T, 4) if achieved is not None else None
+    roofline = {"bound": "valu", "achieved": round(achieved, 2) if achieved is not None else None,
                 "peak": round(LANE_OP_PEAK_T, 2), "unit": "Tlane-op/s", "frac": frac,
-                "valu_busy": busy, "active_lane_fraction": lanes, "pmc_source": pj["_file"] if pj else None,
+                "valu_instructions_per_launch": pj.get("valu_instructions_per_launch") if pj else None,
+                "active_lane_fraction": lanes, "pmc_source": pj["_file"] if pj else None,
+                # the instruction mix issues at about half rate (compares, selects on scalar masks, min / max, shifts, packed fp32:
+                # profiles/r2/valu_issue_cost.txt); against a one-instruction-per-four-cycles ceiling the vector units are busy
+                # `valu_busy_x4` of the time (raw counter ratio, may exceed 1: the mix also holds full-rate instructions)
+                "half_rate_mix": {"valu_busy_x4": busy, "cycle_base": pj.get("cycle_base") if pj else None,
+                                  "effective_clock_GHz": pj.get("effective_clock_GHz") if pj else None,
+                                  "lane_slots_at_half_rate": round(busy * lanes, 4) if busy is not None and lanes is not None else None},
                 "traffic": traffic, "kernel": "render_kernel", "kernel_ms": round(k_ms, 3),
                 "hbm": hbm,
-                "cache_demand": {"bytes_per_launch": alg_bytes, "GBps": round(alg_bytes / k_s / 1e9, 1) if k_ms > 0 else None,
+                "cache_demand": {"note": "requests to L1 / L2 by the in-kernel work counters x bytes per unit; NOT memory-side traffic (that is hbm.fetch / write_bytes_per_launch)",
+                                 "bytes_per_launch": alg_bytes, "GBps": round(alg_bytes / k_s / 1e9, 1) if k_ms > 0 else None,
                                  "GBps_by_array": fetch_demand},
                 "useful_fp32": {"TFLOPs": round(tflops, 3), "frac_of_vector_peak": round(tflops / VALU_PEAK_TFLOPS, 5),
                                 "flops_per_launch": int(alg_flops)}}

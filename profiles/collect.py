@@ -75,8 +75,19 @@ json.dump({
                   "gathers: treat as +-2x",
     "traffic_bytes_per_launch": traffic}, open(f"{out}/traffic{suffix}.json", "w"), indent=1)
 
+def timed_kernel_ms(pass_name):
+    """mean duration of the timed kernel's dispatches in one counter pass (the CSV carries start / end per counter row)"""
+    spans = {}
+    for r in csv.DictReader(open(newest(f"{prof}/pmc_{pass_name}/*/*counter_collection.csv"))):
+        if "render_kernel<false" in r["Kernel_Name"]:
+            spans[r.get("Dispatch_Id")] = (float(r["End_Timestamp"]) - float(r["Start_Timestamp"])) / 1e6
+    return sum(spans.values()) / max(len(spans), 1)
+
+
 acc, kname = timed_kernel_counters(["sq1", "sq2", "tcc1", "tcc2", "tcp"])
 g = acc["GRBM_GUI_ACTIVE"] / 8
+n_disp = dispatches("sq1")
+lanes = acc["SQ_THREAD_CYCLES_VALU"] / (64 * acc["SQ_ACTIVE_INST_VALU"])
 json.dump({
     "workload": workload, "kernel": kname, "source_hash": source_hash,
     "source": f"rocprofv3 --pmc passes of profiles/run_profile.sh {tag} (the benchmark's own launch: same scene, full sample count), "
@@ -89,7 +100,19 @@ json.dump({
     "waitcnt_over_wave_cycles": round(acc["SQ_WAIT_ANY"] / acc["SQ_WAVE_CYCLES"], 3),
     "l2_hit_rate": round(acc["TCC_HIT_sum"] / acc["TCC_REQ_sum"], 3),
     "l1_miss_rate": round(acc["TCP_TCC_READ_REQ_sum"] / acc["TCP_TOTAL_CACHE_ACCESSES_sum"], 3),
-    "waves_per_simd": int(kname.split(",")[1].strip(" >"))}, open(f"{out}/pmc_ratios{suffix}.json", "w"), indent=1)
+    "waves_per_simd": int(kname.split(",")[1].strip(" >")),
+    # what the roofline line is computed from: vector instructions of one launch, the lanes active in them, and the pass's own clock
+    "valu_instructions_per_launch": acc["SQ_INSTS_VALU"] / n_disp,
+    "salu_instructions_per_launch": acc["SQ_INSTS_SALU"] / n_disp,
+    "valu_lane_ops_per_launch": acc["SQ_INSTS_VALU"] / n_disp * 64 * lanes,
+    "kernel_ms_in_pass": {p: round(timed_kernel_ms(p), 3) for p in ("sq1", "tcp")},
+    "cycle_base": "GRBM_GUI_ACTIVE / 8 (the counter sums the 8 XCDs)",
+    "cycles_per_launch": g / dispatches("tcp"),
+    "effective_clock_GHz": round(g / dispatches("tcp") / (timed_kernel_ms("tcp") * 1e6), 3),
+    "raw": {k: acc[k] for k in ("SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_THREAD_CYCLES_VALU", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_INSTS_SALU",
+                                "SQ_WAIT_INST_ANY", "SQ_WAIT_ANY", "SQ_ACTIVE_INST_ANY", "GRBM_GUI_ACTIVE", "TCC_HIT_sum", "TCC_MISS_sum", "TCC_REQ_sum",
+                                "TCP_TOTAL_CACHE_ACCESSES_sum", "TCP_TCC_READ_REQ_sum") if k in acc}},
+    open(f"{out}/pmc_ratios{suffix}.json", "w"), indent=1)
 
 cfgs = []
 for w in () if suffix else ("cornellbox", "teapot", "dragon", "hcandersen", "synthetic"):
