@@ -270,7 +270,7 @@ def main():
     lane_ops = pj.get("valu_lane_ops_per_launch") if pj else None
     achieved = lane_ops / k_s / 1e12 if lane_ops and k_ms > 0 else None
     frac = round(achieved / LANE_OP_PEAK_T, 4) if achieved is not None else None
-    roofline = {"bound": "valu", "achieved": round(achieved, 2) if achieved is not None else None,
+    roofline = {"bound": "valu-issue", "achieved": round(achieved, 2) if achieved is not None else None,
                 "peak": round(LANE_OP_PEAK_T, 2), "unit": "Tlane-op/s", "frac": frac,
                 "valu_instructions_per_launch": pj.get("valu_instructions_per_launch") if pj else None,
                 "active_lane_fraction": lanes, "pmc_source": pj["_file"] if pj else None,

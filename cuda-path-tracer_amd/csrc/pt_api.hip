@@ -3,6 +3,7 @@
  * closest-hit and render entry points, device-memory helpers.  Host code only (kernels live in
  * pt_kernels.hip and pt_post.hip).
  */
+#include <algorithm>
 #include <cfloat>
 #include <cmath>
 #include <cstdio>
@@ -720,6 +721,7 @@ int plan_render(pt_scene *scene, const pt_camera *camera, uint32_t seed, int sam
     p.mtiles_y = (p.tiles_y + 7) / 8;
     const int n_slices = p.plan.n_split * p.plan.slices_per_split;
     if (n_slices > kMaxSlices) PT_FAIL("pt_render_accumulate: slice plan exceeds the slice table");
+    p.n_slices = n_slices;
     p.div_slices = make_udiv((uint32_t)n_slices);
     p.div_mtiles_x = make_udiv((uint32_t)p.mtiles_x);
     for (int k = 0; k < n_slices; k++) {
@@ -738,16 +740,23 @@ int plan_render(pt_scene *scene, const pt_camera *camera, uint32_t seed, int sam
     return 0;
 }
 
+/* (the message is only put together when a check fails: a successful call touches no heap) */
+int fail_arg(const char *who, const char *what) {
+    char buf[160];
+    snprintf(buf, sizeof buf, "%s: %s", who, what);
+    set_error(buf);
+    return 1;
+}
+
 int check_render_args(const char *who, pt_scene *scene, const pt_camera *camera, int sample_begin, int sample_end, int n_split,
                       float *d_split) {
-    const std::string w(who);
-    if (!scene || !camera || !d_split) PT_FAIL(w + ": null argument");
-    if (!scene->committed) PT_FAIL(w + ": scene not committed");
-    if (camera->res_x <= 0 || camera->res_y <= 0) PT_FAIL(w + ": empty image");
-    if (camera->res_x > 0xFFFF || camera->res_y > 0xFFFF) PT_FAIL(w + ": image larger than 65535 pixels on a side");
-    if (sample_begin < 0 || sample_end < sample_begin) PT_FAIL(w + ": bad sample range");
-    if (n_split < 1 || n_split > 64) PT_FAIL(w + ": n_split must be in [1,64]");
-    if (!is_device_pointer(d_split)) PT_FAIL(w + ": d_split must be a device pointer");
+    if (!scene || !camera || !d_split) return fail_arg(who, "null argument");
+    if (!scene->committed) return fail_arg(who, "scene not committed");
+    if (camera->res_x <= 0 || camera->res_y <= 0) return fail_arg(who, "empty image");
+    if (camera->res_x > 0xFFFF || camera->res_y > 0xFFFF) return fail_arg(who, "image larger than 65535 pixels on a side");
+    if (sample_begin < 0 || sample_end < sample_begin) return fail_arg(who, "bad sample range");
+    if (n_split < 1 || n_split > 64) return fail_arg(who, "n_split must be in [1,64]");
+    if (!is_device_pointer(d_split)) return fail_arg(who, "d_split must be a device pointer");
     return 0;
 }
 
@@ -821,23 +830,52 @@ int pt_render_accumulate_noalloc(pt_scene *scene, const pt_camera *camera, uint3
     RenderParams p;
     size_t need = 0;
     if (plan_render(scene, camera, seed, sample_begin, sample_end, n_split, p, &need)) return 1;
-    if (need > kScratchBytes - kScratchTicketBytes) {
-        char buf[256];
-        snprintf(buf, sizeof buf,
-                 "pt_render_accumulate_noalloc: %zu bytes of slice partials (%d slices x %lld pixels x 12) exceed the fixed scratch of %zu bytes: "
-                 "render fewer samples or a smaller frame per call",
-                 need, p.plan.n_split * p.plan.slices_per_split, (long long)n_pixels, kScratchBytes - kScratchTicketBytes);
-        PT_FAIL(buf);
-    }
     unsigned char *base = scene->scratch;        /* this device's copy of the scratch array, resolved at commit */
     if (!base) PT_FAIL("pt_render_accumulate_noalloc: scratch address not resolved");
     p.tickets = reinterpret_cast<uint32_t *>(base);
-    p.partials = reinterpret_cast<float *>(base + kScratchTicketBytes);
-    /* the array keeps the previous call's contents: the cursors must start at zero; every partial the
-     * compounding kernel reads is written by the render kernel first */
-    PT_HIP(hipMemsetAsync(p.tickets, 0, (kMaxQueues + 1) * sizeof(uint32_t), stream));
-    if (launch_render(p, scene->n_cu, kMaxQueues, scene->heavy, stream)) return 1;
-    if (launch_compound_partials(p.partials, d_split, n_pixels, p.plan, stream)) return 1;
+    float *images = reinterpret_cast<float *>(base + kScratchTicketBytes);
+    const size_t image_bytes = (size_t)n_pixels * 12;
+    const size_t max_images = (kScratchBytes - kScratchTicketBytes) / image_bytes;
+    const int n_slices = p.n_slices;
+    if ((size_t)n_slices <= max_images) {
+        /* the whole plan at once, as pt_render_accumulate does.  The array keeps the previous call's contents: the cursors
+         * must start at zero; every partial the compounding kernel reads is written by the render kernel first */
+        p.partials = images;
+        if (launch_zero_words(p.tickets, kMaxQueues + 1, stream)) return 1;
+        if (launch_render(p, scene->n_cu, kMaxQueues, scene->heavy, stream)) return 1;
+        if (launch_compound_partials(p.partials, d_split, n_pixels, p.plan, stream)) return 1;
+        return 0;
+    }
+    /* The plan's slices do not fit the scratch together: render them a few at a time.  Image 0 of the scratch carries the
+     * running sum of the current split buffer's slices, the other images take the slices of one launch; the sums are the
+     * additions pt_render_accumulate's compounding kernel makes, in its order -- (((0 + p0) + p1) + ...), then split += sum --
+     * so the split buffers end up with the same bits as after ONE pt_render_accumulate call with the same arguments. */
+    if (max_images < 2) {
+        char buf[256];
+        snprintf(buf, sizeof buf,
+                 "pt_render_accumulate_noalloc: a frame of %lld pixels needs two images of %zu bytes in the fixed scratch of %zu bytes "
+                 "(one slice of samples and the running sum): render a smaller frame per call",
+                 (long long)n_pixels, image_bytes, kScratchBytes - kScratchTicketBytes);
+        PT_FAIL(buf);
+    }
+    const int per_launch = (int)std::min<size_t>(max_images - 1, (size_t)kMaxSlices);
+    const int sps = p.plan.slices_per_split;
+    float *sum = images, *parts = images + (size_t)n_pixels * 3;
+    for (int z = 0; z < p.plan.n_split; z++) {
+        for (int j = 0; j < sps; j += per_launch) {
+            const int g = std::min(per_launch, sps - j);
+            RenderParams q = p;
+            q.n_slices = g;
+            q.div_slices = make_udiv((uint32_t)g);
+            for (int k = 0; k < g; k++) slice_range(p.plan, z * sps + j + k, q.slice_s0[k], q.slice_s1[k]);
+            q.n_items = (uint32_t)((uint64_t)p.mtiles_x * p.mtiles_y * 64 * g);
+            q.partials = parts;
+            if (launch_zero_words(q.tickets, kMaxQueues + 1, stream)) return 1;
+            if (launch_render(q, scene->n_cu, kMaxQueues, scene->heavy, stream)) return 1;
+            const bool last = j + g >= sps;
+            if (launch_fold_partials(sum, parts, g, j == 0, last ? d_split + (size_t)z * n_pixels * 3 : nullptr, n_pixels, stream)) return 1;
+        }
+    }
     return 0;
 }
 

@@ -84,6 +84,8 @@ struct RenderParams {
     CamConsts camk;
     uint32_t seed;
     SlicePlan plan;
+    int n_slices;                /* slices this launch renders (the whole plan: n_split * slices_per_split; a group of a plan's slices:
+                                  * fewer): slice k of the launch takes samples [slice_s0[k], slice_s1[k]) and writes partial image k */
     int tiles_x, tiles_y;        /* 8x8-pixel tiles covering the image */
     int mtiles_x, mtiles_y;      /* 8x8-tile macro tiles covering the tiles */
     uint32_t n_items;            /* mtiles_x * mtiles_y * 64 tiles * slices */
@@ -114,6 +116,11 @@ int render_workgroups_per_cu(int max_depth, bool heavy);
 int launch_render(RenderParams p, int n_cu, int max_queues, bool heavy, hipStream_t stream);
 int launch_compound_partials(const float *d_partials, float *d_split, int64_t n_pixels, const SlicePlan &plan,
                              hipStream_t stream);
+/* d_sum = (first ? 0 : d_sum) + d_parts[0] + d_parts[1] + ... in that order (n_parts images of n_pixels); with d_split:
+ * d_split += d_sum afterwards.  The running sum of one split buffer's slices when they are rendered a few at a time. */
+int launch_fold_partials(float *d_sum, const float *d_parts, int n_parts, bool first, float *d_split, int64_t n_pixels, hipStream_t stream);
+/* d_words[0..n) = 0, as a kernel (the allocation-free entry point enqueues kernel launches only) */
+int launch_zero_words(uint32_t *d_words, int n, hipStream_t stream);
 int launch_compound_split(const float *d_split, float *d_out, int64_t n_pixels, int n_split, hipStream_t stream);
 
 } // namespace ptamd

@@ -522,7 +522,7 @@ __global__ void __launch_bounds__(kBlock, WAVES) render_kernel(RenderParams P) {
     CoopLds *coop = coop_area(lds_stack, P.sc.max_depth);
     const int lane = threadIdx.x & 63;
     const int W = P.cam.res_x, H = P.cam.res_y;
-    const int n_slices = P.plan.n_split * P.plan.slices_per_split;
+    const int n_slices = P.n_slices;
     const size_t n_pixels = (size_t)W * (size_t)H;
 
     /* wave-uniform pool: the item this wave is handing out pixels of, decoded once when it is pulled (on the scalar
@@ -724,6 +724,18 @@ __global__ void __launch_bounds__(kBlock) compound_partials_kernel(const float *
     }
 }
 
+/* sum = (first ? 0 : sum) + part[0] + part[1] + ...; split += sum when the split buffer's last slice is among them: the
+ * additions of compound_partials_kernel for one split buffer, in the same order, a few slices at a time */
+__global__ void __launch_bounds__(kBlock) fold_partials_kernel(float *__restrict__ sum, const float *__restrict__ parts, int n_parts, int first,
+                                                               float *__restrict__ split, int64_t n_floats) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n_floats) return;
+    float s = first ? 0.0f : sum[i];
+    for (int j = 0; j < n_parts; j++) s = s + parts[(int64_t)j * n_floats + i];
+    if (split) split[i] = split[i] + s;
+    else sum[i] = s;
+}
+
 /* compound_buffers (src/post_processing.cu:243-256) */
 __global__ void __launch_bounds__(kBlock) compound_split_kernel(const float *__restrict__ split, float *__restrict__ out,
                                                                 int64_t n_floats, int n_split) {
@@ -844,6 +856,26 @@ int launch_compound_partials(const float *d_partials, float *d_split, int64_t n_
     const int64_t n_floats = n_pixels * 3;
     hipLaunchKernelGGL(compound_partials_kernel, dim3((unsigned)((n_floats + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream,
                        d_partials, d_split, n_floats, plan.n_split, plan.slices_per_split);
+    PT_HIP(hipGetLastError());
+    return 0;
+}
+
+__global__ void __launch_bounds__(kBlock) zero_words_kernel(uint32_t *__restrict__ p, int n) {
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i < n) p[i] = 0u;
+}
+
+int launch_zero_words(uint32_t *d_words, int n, hipStream_t stream) {
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(zero_words_kernel, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, d_words, n);
+    PT_HIP(hipGetLastError());
+    return 0;
+}
+
+int launch_fold_partials(float *d_sum, const float *d_parts, int n_parts, bool first, float *d_split, int64_t n_pixels, hipStream_t stream) {
+    const int64_t n_floats = n_pixels * 3;
+    hipLaunchKernelGGL(fold_partials_kernel, dim3((unsigned)((n_floats + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream, d_sum, d_parts, n_parts,
+                       first ? 1 : 0, d_split, n_floats);
     PT_HIP(hipGetLastError());
     return 0;
 }

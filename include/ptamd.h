@@ -182,16 +182,20 @@ int pt_render_accumulate(pt_scene *scene, const pt_camera *camera, uint32_t seed
                          pt_counters *counters, void *stream);
 /* Variant of pt_render_accumulate that allocates nothing.  It has no counterpart in the reference; it is
  * for callers that cannot call hipMalloc: code under HIP graph capture, tight serving loops, harnesses
- * that forbid allocation.  Same arguments, same kernels and the same image bits as pt_render_accumulate
- * (without counters), but the render kernel's work-queue cursors and slice partials live in a fixed
- * array of PT_NOALLOC_SCRATCH_BYTES in the library's device image instead of a workspace grown with
- * hipMalloc; every GPU the library runs on holds that array until the process ends.  A launch needs
- * slices x W x H x 12 bytes of partials, where slices = n_split x min(64 / n_split,
- * ceil(ceil(samples / n_split) / 8)); the call fails with a clear error when that exceeds
- * pt_noalloc_max_partial_bytes() (e.g. 1920x1080: two slices = up to 16 samples per call with n_split 1;
- * 640x360: 24 slices).  All calls on one GPU share the array, whatever their scene or stream: calls
- * that overlap in time on one GPU race and produce wrong images -- serialise them (one stream, or
- * events). */
+ * that forbid allocation.  Same arguments, same kernels and the same split-buffer bits as ONE
+ * pt_render_accumulate call with these arguments (without counters), but the render kernel's work-queue
+ * cursors and slice partials live in a fixed array of PT_NOALLOC_SCRATCH_BYTES in the library's device
+ * image instead of a workspace grown with hipMalloc.  Loading the library costs that much memory on every
+ * GPU it runs on, until the process ends, whether or not this entry point is called.  The plan of a call
+ * has slices = n_split x min(64 / n_split, ceil(ceil(samples / n_split) / 8)) slices of samples, each with
+ * a partial image of W x H x 12 bytes.  When they fit pt_noalloc_max_partial_bytes() together (640x360: 24
+ * slices) the call is one launch; otherwise it renders as many slices per launch as fit beside one image
+ * that carries the running sum of the current split buffer (1920x1080: one slice per launch), adding them
+ * up in pt_render_accumulate's order.  It fails, with a clear error and nothing written, only when two
+ * images do not fit (frames of more than 2.79 M pixels).  No host or device allocation on the successful
+ * path; all work is enqueued on `stream` as kernel launches (legal under stream capture; the cursors are
+ * zeroed by a kernel: a captured memset in front of the first launch did not take effect on replay).  All calls on one GPU share the array, whatever their scene or stream: calls that overlap in
+ * time on one GPU race and produce wrong images -- serialise them (one stream, or events). */
 #define PT_NOALLOC_SCRATCH_BYTES (64u << 20)
 int pt_render_accumulate_noalloc(pt_scene *scene, const pt_camera *camera, uint32_t seed,
                                  int sample_begin, int sample_end, int n_split, float *d_split,
