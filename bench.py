@@ -155,16 +155,37 @@ def main():
     cfg = S.CONFIGS[args.workload]
     res = tuple(int(x) for x in args.res.split("x")) if args.res else cfg["res"]
     spp = ptdist.effective_spp(args.spp if args.spp else cfg["spp"])
-    t0 = time.time()
-    desc = cfg["builder"](res=res)
-    t_gen = time.time() - t0
-    t0 = time.time()
-    scene, cam = ptamd.scene_from_description(desc, device=dev)
+    # The scene is generated, and its octrees are built, ONCE per node: by rank 0, which hands the built scene to the other
+    # ranks through a file on the RAM-backed /dev/shm (pt_scene_save / pt_scene_load); they only upload it.
+    desc, t_gen, t0 = None, 0.0, time.time()
+    share = os.path.join("/dev/shm" if os.path.isdir("/dev/shm") else "/tmp", f"ptamd_bench_{os.environ.get('MASTER_PORT', '0')}_{args.workload}.scene")
+    if rank == 0:
+        desc = cfg["builder"](res=res)
+        t_gen = time.time() - t0
+        t0 = time.time()
+        scene, cam = ptamd.scene_from_description(desc, device=dev)
+        meshes = [e for e in desc["entities"] if e["kind"] == "mesh"]
+        meta = {"camera": desc["camera"], "n_entities": len(desc["entities"]), "n_mesh": len(meshes),
+                "depth": max([e.get("octree_depth", 0) for e in meshes] or [0]), "triangles": int(sum(len(e["tri"]) for e in meshes))}
+        if world > 1:
+            scene.save(share)
+    if world > 1:
+        box = [meta if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)          # (also the signal that the file is complete)
+        meta = box[0]
+        if rank != 0:
+            t0 = time.time()
+            scene = ptamd.load_scene(share, device=dev)
+            c = meta["camera"]
+            cam = ptamd.make_camera(c["position"], c["direction"], c["res"], c["focal_length"], c["aperture"], c["focus_distance"])
+        dist.barrier()
+        if rank == 0 and os.path.exists(share):
+            os.remove(share)
     t_upload = time.time() - t0
     n_pixels = res[0] * res[1]
     n_split = 4
-    n_entities = len(desc["entities"])
-    s_begin, s_end = ptdist.shard_samples(spp, rank, world)
+    n_entities = meta["n_entities"]
+    (s_begin, s_end), tiles = ptdist.shard_work(spp, rank, world)
 
     split = torch.zeros((n_split, res[1], res[0], 3), dtype=torch.float32, device=f"cuda:{dev}")
     local_sum = torch.zeros((res[1], res[0], 3), dtype=torch.float32, device=f"cuda:{dev}")
@@ -173,7 +194,7 @@ def main():
 
     def step(want_counters=False):
         split.zero_()
-        cnt = scene.render_accumulate(cam, 1337, s_begin, s_end, n_split, split.data_ptr(), want_counters, stream)
+        cnt = scene.render_accumulate(cam, 1337, s_begin, s_end, n_split, split.data_ptr(), want_counters, stream, tiles=tiles)
         ptamd.check(L.pt_compound_buffers(dev, split.data_ptr(), local_sum.data_ptr(), n_pixels, n_split, stream))
         if use_dist:
             if args.backend == "nccl":
@@ -216,6 +237,12 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dist.all_reduce(cvec, op=dist.ReduceOp.SUM)
     elapsed = float(t.item())
+    # per rank: seconds from scene description (rank 0) or scene file (others) to the committed scene, octrees built
+    build_info = [(round(t_upload, 3), ptamd.octree_builds())]
+    if use_dist and world > 1:
+        gathered = [None] * world
+        dist.all_gather_object(gathered, build_info[0])
+        build_info = gathered
     total_counters = {k: int(v) for k, v in zip(ptamd.COUNTER_NAMES, cvec.tolist())}
 
     ms_per_step = 1000.0 * elapsed / max(args.steps, 1)
@@ -226,7 +253,7 @@ def main():
     plan_slices = n_split * min(max(1, 64 // n_split), max(1, (-(-(s_end - s_begin) // n_split) + 7) // 8))   # make_slice_plan
     k_ms = float(np.mean(kernel_ms)) if kernel_ms else float("nan")
     k_s = k_ms / 1000.0
-    workload_name = f"{args.workload} {res[0]}x{res[1]} {spp}spp octree-depth-{max([e.get('octree_depth', 0) for e in desc['entities'] if e['kind'] == 'mesh'] or [0])}"
+    workload_name = f"{args.workload} {res[0]}x{res[1]} {spp}spp octree-depth-{meta['depth']}"
     # (a) demand on the scene arrays, by array: counters of this launch x bytes one unit of work needs.  These
     # are requests to the cache hierarchy (the geometry working set is L1 / L2 resident), not HBM traffic.
     hits = counters["segments"] - counters["env_lookups"] if counters["env_lookups"] else counters["segments"]
@@ -262,7 +289,7 @@ def main():
     # (d) what binds: vector-instruction issue.  achieved = lane-operations of one launch (vector instructions x 64 x the mean
     # share of lanes active in one: separate --pmc passes over this very launch, a property of the work, not of the run) / the
     # kernel's duration measured live here; peak = every SIMD retiring 32 lanes per cycle at the nominal clock.
-    n_mesh = sum(1 for e in desc["entities"] if e["kind"] == "mesh")
+    n_mesh = meta["n_mesh"]
     alg_flops = algorithmic_flops(counters, n_mesh)
     tflops = alg_flops / k_s / 1e12 if k_ms > 0 else 0.0
     busy = pj.get("valu_busy") if pj else None
@@ -339,14 +366,16 @@ def main():
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": workload_name,
-                       "triangles": int(sum(len(e["tri"]) for e in desc["entities"] if e["kind"] == "mesh")),
-                       "spp": spp, "samples_per_rank": s_end - s_begin, "parallelism": f"sample-shard x{world}"},
+                       "triangles": meta["triangles"],
+                       "spp": spp, "samples_per_rank": s_end - s_begin,
+                       "parallelism": f"sample-shard x{world}" if tiles[1] == 1 else f"tile-shard x{world}"},
             "time_to_spp_s": round(ms_per_step / 1000.0, 4),
             "msegments_per_s": round(total_counters["segments"] / (ms_per_step / 1000.0) / 1e6, 2),
             "counters": total_counters, "schedule": schedule, "launch": launch,
             "roofline": roofline, "pmc": pmc, "cpu_baseline": cpu_baseline, "parity_vs_oracle": parity,
             "post_chain_ms": None if post_ms is None else round(post_ms, 2),
             "scene_gen_s": round(t_gen, 2), "scene_build_upload_s": round(t_upload, 2),
+            "scene_by_rank": {"build_upload_s": [b[0] for b in build_info], "octree_builds": [b[1] for b in build_info]},
             "scene_device_bytes": sbytes, "library_source_hash": ptamd.source_hash(), "backend": args.backend if use_dist else None,
         }
         print(json.dumps(line), flush=True)

@@ -4,6 +4,7 @@
  * pt_kernels.hip and pt_post.hip).
  */
 #include <algorithm>
+#include <atomic>
 #include <cfloat>
 #include <cmath>
 #include <cstdio>
@@ -21,6 +22,7 @@
 namespace ptamd {
 
 static thread_local std::string g_error;
+static std::atomic<uint64_t> g_octree_builds{0};      /* octrees built by this process (pt_octree_builds) */
 
 void set_error(const std::string &msg) { g_error = msg; }
 
@@ -60,9 +62,10 @@ using namespace ptamd;
 struct pt_scene {
     int device = 0;
     int n_cu = 256;
-    std::vector<MaterialHost> materials;
-    std::vector<std::unique_ptr<EntityHost>> entities;
-    std::vector<float> hdri;
+    /* host-side description: shared, never modified once added, so that pt_scene_clone can hand it to a scene on another GPU */
+    std::vector<std::shared_ptr<const MaterialHost>> materials;
+    std::vector<std::shared_ptr<const EntityHost>> entities;
+    std::shared_ptr<const std::vector<float>> hdri;
     int hdri_w = 0, hdri_h = 0;
     float hdri_exposure = 1.0f, hdri_contrast = 1.0f, hdri_rot = 0.0f;
     bool has_hdri = false, hdri_smooth = false;
@@ -292,7 +295,7 @@ int pt_scene_add_material(pt_scene *scene, const pt_material_desc *desc, int *ma
         const size_t n = (size_t)w[k] * h[k] * (k == 3 ? 1 : 3);
         m.maps[k].assign(src[k], src[k] + n);
     }
-    scene->materials.push_back(std::move(m));
+    scene->materials.push_back(std::make_shared<const MaterialHost>(std::move(m)));
     scene->committed = false;
     if (material_out) *material_out = (int)scene->materials.size() - 1;
     return 0;
@@ -329,9 +332,10 @@ int pt_scene_add_mesh(pt_scene *scene, const float *positions, const float *norm
     padded_aabb(positions, n_vertices, e->aabb_min, e->aabb_max);
     if (octree_depth > 0) {
         build_octree(e->positions.data(), e->tri.data(), n_triangles, e->aabb_min, e->aabb_max, octree_depth, e->tree);
+        g_octree_builds.fetch_add(1, std::memory_order_relaxed);
         if (e->tree.nodes.size() >= (1ull << 29)) PT_FAIL("pt_scene_add_mesh: octree too large (node index needs 29 bits)");
     }
-    scene->entities.push_back(std::move(e));
+    scene->entities.push_back(std::shared_ptr<const EntityHost>(std::move(e)));
     scene->committed = false;
     if (entity_out) *entity_out = (int)scene->entities.size() - 1;
     return 0;
@@ -345,7 +349,7 @@ int pt_scene_add_sphere(pt_scene *scene, const float center[3], float radius, in
     e->material = material;
     memcpy(e->center, center, sizeof(float) * 3);
     e->radius = radius;
-    scene->entities.push_back(std::move(e));
+    scene->entities.push_back(std::shared_ptr<const EntityHost>(std::move(e)));
     scene->committed = false;
     if (entity_out) *entity_out = (int)scene->entities.size() - 1;
     return 0;
@@ -356,13 +360,209 @@ int pt_scene_set_hdri(pt_scene *scene, const float *rgb, int w, int h, float exp
     if (!rgb || w <= 0 || h <= 0) PT_FAIL("pt_scene_set_hdri: empty image");
     if ((unsigned long long)w * (unsigned long long)h * 12ull >= (1ull << 32)) PT_FAIL("pt_scene_set_hdri: image of 4 GiB or more (texels are addressed by 32-bit byte offsets)");
     if (!(rot_offset >= 0.0f)) PT_FAIL("pt_scene_set_hdri: rotation must be >= 0");   /* src/scene.cu:53 */
-    scene->hdri.assign(rgb, rgb + (size_t)w * h * 3);
+    scene->hdri = std::make_shared<const std::vector<float>>(rgb, rgb + (size_t)w * h * 3);
     scene->hdri_w = w; scene->hdri_h = h;
     scene->hdri_exposure = exposure; scene->hdri_contrast = contrast;
     scene->hdri_rot = fmodf(rot_offset, 1.0f);                                        /* src/scene.cu:54 */
     scene->hdri_smooth = smooth != 0;
     scene->has_hdri = true;
     scene->committed = false;
+    return 0;
+}
+
+int pt_octree_builds(uint64_t *count) {
+    if (!count) PT_FAIL("pt_octree_builds: null argument");
+    *count = g_octree_builds.load(std::memory_order_relaxed);
+    return 0;
+}
+
+int pt_scene_clone(pt_scene *src, int device, pt_scene **out) {
+    if (!src || !out) PT_FAIL("pt_scene_clone: null argument");
+    pt_scene *s = nullptr;
+    if (pt_scene_create(device, &s)) return 1;
+    s->materials = src->materials;
+    s->entities = src->entities;
+    s->hdri = src->hdri;
+    s->hdri_w = src->hdri_w; s->hdri_h = src->hdri_h;
+    s->hdri_exposure = src->hdri_exposure; s->hdri_contrast = src->hdri_contrast; s->hdri_rot = src->hdri_rot;
+    s->has_hdri = src->has_hdri; s->hdri_smooth = src->hdri_smooth;
+    s->heavy = src->heavy; s->quorum = src->quorum; s->leaf_quota = src->leaf_quota;
+    s->build_fixed = src->build_fixed; s->quorum_fixed = src->quorum_fixed; s->leaf_quota_fixed = src->leaf_quota_fixed;
+    *out = s;
+    return 0;
+}
+
+}  // extern "C"
+
+namespace {
+
+/* scene files (pt_scene_save / pt_scene_load): the host-side description with its built octrees, little endian, as
+ * { "PTAMDSC1", counts, then per material / entity a fixed header and its arrays } */
+struct FileOut {
+    FILE *f;
+    bool ok = true;
+    void raw(const void *p, size_t n) { if (ok && n && fwrite(p, 1, n, f) != n) ok = false; }
+    template <typename T> void pod(const T &v) { raw(&v, sizeof v); }
+    template <typename T> void vec(const std::vector<T> &v) { pod((uint64_t)v.size()); raw(v.data(), v.size() * sizeof(T)); }
+};
+struct FileIn {
+    FILE *f;
+    uint64_t left;      /* bytes of the file not read yet: bounds every array length before it is allocated */
+    bool ok = true;
+    void raw(void *p, size_t n) {
+        if (!ok) return;
+        if (n > left || (n && fread(p, 1, n, f) != n)) { ok = false; return; }
+        left -= n;
+    }
+    template <typename T> void pod(T &v) { raw(&v, sizeof v); }
+    template <typename T> void vec(std::vector<T> &v) {
+        uint64_t n = 0;
+        pod(n);
+        if (!ok || n > left / sizeof(T)) { ok = false; return; }
+        v.resize((size_t)n);
+        raw(v.data(), (size_t)n * sizeof(T));
+    }
+};
+const char kSceneMagic[8] = {'P', 'T', 'A', 'M', 'D', 'S', 'C', '1'};
+
+struct MaterialFileHeader { float albedo[3], specular[3], emission, smoothness; int32_t smooth_shading, w[4], h[4]; };
+struct EntityFileHeader { int32_t shape, material, octree_depth, tree_depth; float aabb_min[3], aabb_max[3], center[3], radius; int64_t max_leaf; };
+struct HdriFileHeader { int32_t has, w, h, smooth; float exposure, contrast, rot; };
+
+}  // namespace
+
+extern "C" {
+
+int pt_scene_save(pt_scene *scene, const char *path) {
+    if (!scene || !path) PT_FAIL("pt_scene_save: null argument");
+    FILE *f = fopen(path, "wb");
+    if (!f) PT_FAIL(std::string("pt_scene_save: cannot open ") + path);
+    FileOut o{f};
+    o.raw(kSceneMagic, sizeof kSceneMagic);
+    o.pod((uint32_t)scene->materials.size());
+    for (const auto &m : scene->materials) {
+        MaterialFileHeader h;
+        memset(&h, 0, sizeof h);
+        memcpy(h.albedo, m->d.albedo, 12); memcpy(h.specular, m->d.specular, 12);
+        h.emission = m->d.emission; h.smoothness = m->d.smoothness; h.smooth_shading = m->d.smooth_shading;
+        const int w[4] = {m->d.albedo_w, m->d.specular_w, m->d.normal_w, m->d.smoothness_w};
+        const int hh[4] = {m->d.albedo_h, m->d.specular_h, m->d.normal_h, m->d.smoothness_h};
+        for (int k = 0; k < 4; k++) { h.w[k] = m->maps[k].empty() ? 0 : w[k]; h.h[k] = m->maps[k].empty() ? 0 : hh[k]; }
+        o.pod(h);
+        for (int k = 0; k < 4; k++) o.vec(m->maps[k]);
+    }
+    o.pod((uint32_t)scene->entities.size());
+    for (const auto &e : scene->entities) {
+        EntityFileHeader h;
+        memset(&h, 0, sizeof h);
+        h.shape = e->shape; h.material = e->material; h.octree_depth = e->octree_depth; h.tree_depth = e->tree.max_depth;
+        memcpy(h.aabb_min, e->aabb_min, 12); memcpy(h.aabb_max, e->aabb_max, 12); memcpy(h.center, e->center, 12);
+        h.radius = e->radius; h.max_leaf = e->tree.max_leaf;
+        o.pod(h);
+        o.vec(e->positions); o.vec(e->normals); o.vec(e->uvs); o.vec(e->tri);
+        o.vec(e->tree.nodes); o.vec(e->tree.leaf_tris); o.vec(e->tree.nodes_per_depth);
+    }
+    HdriFileHeader hh;
+    memset(&hh, 0, sizeof hh);
+    hh.has = scene->has_hdri ? 1 : 0; hh.w = scene->hdri_w; hh.h = scene->hdri_h; hh.smooth = scene->hdri_smooth ? 1 : 0;
+    hh.exposure = scene->hdri_exposure; hh.contrast = scene->hdri_contrast; hh.rot = scene->hdri_rot;
+    o.pod(hh);
+    if (scene->has_hdri) o.vec(*scene->hdri);
+    const bool closed = fclose(f) == 0;
+    if (!o.ok || !closed) { remove(path); PT_FAIL(std::string("pt_scene_save: write failed: ") + path); }
+    return 0;
+}
+
+int pt_scene_load(int device, const char *path, pt_scene **out) {
+    if (!path || !out) PT_FAIL("pt_scene_load: null argument");
+    FILE *f = fopen(path, "rb");
+    if (!f) PT_FAIL(std::string("pt_scene_load: cannot open ") + path);
+    fseek(f, 0, SEEK_END);
+    const long size = ftell(f);
+    fseek(f, 0, SEEK_SET);
+    FileIn in{f, size > 0 ? (uint64_t)size : 0};
+    pt_scene *s = nullptr;
+    const auto fail = [&](const char *what) {
+        fclose(f);
+        if (s) pt_scene_destroy(s);
+        set_error(std::string("pt_scene_load: ") + what + ": " + path);
+        return 1;
+    };
+    char magic[8];
+    in.raw(magic, sizeof magic);
+    if (!in.ok || memcmp(magic, kSceneMagic, sizeof magic) != 0) return fail("not a scene file");
+    if (pt_scene_create(device, &s)) { fclose(f); return 1; }
+    uint32_t n_mat = 0, n_ent = 0;
+    in.pod(n_mat);
+    for (uint32_t i = 0; in.ok && i < n_mat; i++) {
+        MaterialFileHeader h;
+        in.pod(h);
+        MaterialHost m;
+        memset(&m.d, 0, sizeof m.d);
+        memcpy(m.d.albedo, h.albedo, 12); memcpy(m.d.specular, h.specular, 12);
+        m.d.emission = h.emission; m.d.smoothness = h.smoothness; m.d.smooth_shading = h.smooth_shading;
+        m.d.albedo_w = h.w[0]; m.d.specular_w = h.w[1]; m.d.normal_w = h.w[2]; m.d.smoothness_w = h.w[3];
+        m.d.albedo_h = h.h[0]; m.d.specular_h = h.h[1]; m.d.normal_h = h.h[2]; m.d.smoothness_h = h.h[3];
+        for (int k = 0; k < 4 && in.ok; k++) {
+            in.vec(m.maps[k]);
+            if (in.ok && h.w[k] >= 0 && h.h[k] >= 0 && m.maps[k].size() != (size_t)h.w[k] * (size_t)h.h[k] * (k == 3 ? 1 : 3)) in.ok = false;
+        }
+        s->materials.push_back(std::make_shared<const MaterialHost>(std::move(m)));
+    }
+    in.pod(n_ent);
+    for (uint32_t i = 0; in.ok && i < n_ent; i++) {
+        EntityFileHeader h;
+        in.pod(h);
+        std::unique_ptr<EntityHost> e(new EntityHost());
+        e->shape = h.shape; e->material = h.material; e->octree_depth = h.octree_depth; e->tree.max_depth = h.tree_depth;
+        memcpy(e->aabb_min, h.aabb_min, 12); memcpy(e->aabb_max, h.aabb_max, 12); memcpy(e->center, h.center, 12);
+        e->radius = h.radius; e->tree.max_leaf = h.max_leaf;
+        in.vec(e->positions); in.vec(e->normals); in.vec(e->uvs); in.vec(e->tri);
+        in.vec(e->tree.nodes); in.vec(e->tree.leaf_tris); in.vec(e->tree.nodes_per_depth);
+        if (!in.ok) break;
+        /* what pt_scene_add_mesh checks, and what the flattening in pt_scene_commit indexes */
+        const size_t nv = e->positions.size() / 3, nt = e->tri.size() / 6, nuv = e->uvs.size() / 2;
+        bool good = h.material >= 0 && h.material < (int)s->materials.size() && (h.shape == PT_SHAPE_SPHERE || h.shape == PT_SHAPE_MESH) &&
+                    h.octree_depth >= 0 && h.octree_depth <= PT_MAX_OCTREE_DEPTH;
+        if (good && h.shape == PT_SHAPE_MESH) {
+            good = nv > 0 && nt > 0 && e->positions.size() == 3 * nv && e->normals.size() == 3 * nv && e->tri.size() == 6 * nt && e->uvs.size() == 2 * nuv;
+            for (size_t t = 0; good && t < nt; t++)
+                for (int k = 0; k < 3; k++) {
+                    good = good && e->tri[6 * t + k] >= 0 && (size_t)e->tri[6 * t + k] < nv;
+                    if (nuv) good = good && e->tri[6 * t + 3 + k] >= 0 && (size_t)e->tri[6 * t + 3 + k] < nuv;
+                }
+            if (good && h.octree_depth > 0) {
+                const FlatOctree &T = e->tree;
+                good = T.max_depth == h.octree_depth && T.nodes_per_depth.size() == (size_t)T.max_depth + 1 && !T.nodes.empty() && T.nodes.size() < (1ull << 29);
+                int64_t total = 0;
+                for (size_t d = 0; good && d < T.nodes_per_depth.size(); d++) { good = T.nodes_per_depth[d] >= 0; total += T.nodes_per_depth[d]; }
+                good = good && (uint64_t)total == T.nodes.size();
+                const size_t n_inner = good ? T.nodes.size() - (size_t)T.nodes_per_depth[T.max_depth] : 0;
+                for (size_t n = 0; good && n < T.nodes.size(); n++) {
+                    const PtNode &nd = T.nodes[n];
+                    if (n < n_inner) good = nd.b < 256u && (uint64_t)nd.a + (uint32_t)__builtin_popcount(nd.b) <= T.nodes.size() && (nd.b == 0u || nd.a > n);
+                    else good = (uint64_t)nd.a + nd.b <= T.leaf_tris.size();
+                }
+                for (size_t k = 0; good && k < T.leaf_tris.size(); k++) good = T.leaf_tris[k] >= 0 && (size_t)T.leaf_tris[k] < nt;
+            }
+        }
+        if (!good) { in.ok = false; break; }
+        s->entities.push_back(std::shared_ptr<const EntityHost>(std::move(e)));
+    }
+    HdriFileHeader hh;
+    memset(&hh, 0, sizeof hh);
+    in.pod(hh);
+    if (in.ok && hh.has) {
+        std::vector<float> img;
+        in.vec(img);
+        if (in.ok && (hh.w <= 0 || hh.h <= 0 || img.size() != (size_t)hh.w * (size_t)hh.h * 3 || (uint64_t)hh.w * (uint64_t)hh.h * 12ull >= (1ull << 32))) in.ok = false;
+        s->hdri = std::make_shared<const std::vector<float>>(std::move(img));
+        s->hdri_w = hh.w; s->hdri_h = hh.h; s->hdri_smooth = hh.smooth != 0; s->has_hdri = true;
+        s->hdri_exposure = hh.exposure; s->hdri_contrast = hh.contrast; s->hdri_rot = hh.rot;
+    }
+    if (!in.ok) return fail("truncated or inconsistent scene file");
+    fclose(f);
+    *out = s;
     return 0;
 }
 
@@ -384,7 +584,7 @@ int pt_scene_commit(pt_scene *scene) {
         memset(&e, 0, sizeof e);
         e.shape = h.shape;
         e.material = h.material;
-        e.smooth_shading = scene->materials[h.material].d.smooth_shading ? 1 : 0;
+        e.smooth_shading = scene->materials[h.material]->d.smooth_shading ? 1 : 0;
         memcpy(e.center, h.center, sizeof e.center);
         e.radius = h.radius;
         if (h.shape == PT_SHAPE_MESH) {
@@ -439,7 +639,7 @@ int pt_scene_commit(pt_scene *scene) {
     const bool plain_layouts = plain_env && plain_env[0] == '1';
     std::vector<PtMaterial> mats(scene->materials.size());
     for (size_t i = 0; i < scene->materials.size(); i++) {
-        const MaterialHost &h = scene->materials[i];
+        const MaterialHost &h = *scene->materials[i];
         PtMaterial m;
         memset(&m, 0, sizeof m);
         memcpy(m.albedo, h.d.albedo, 12);
@@ -516,8 +716,8 @@ int pt_scene_commit(pt_scene *scene) {
             void *d_img = nullptr, *d_quads = nullptr;
             int rc = 0;
             do {
-                if (hipMalloc(&d_img, scene->hdri.size() * sizeof(float)) != hipSuccess) { rc = hip_fail(hipErrorOutOfMemory, "hipMalloc hdri", __FILE__, __LINE__); break; }
-                if (hipMemcpy(d_img, scene->hdri.data(), scene->hdri.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) { rc = 1; set_error("pt_scene_commit: environment map upload failed"); break; }
+                if (hipMalloc(&d_img, scene->hdri->size() * sizeof(float)) != hipSuccess) { rc = hip_fail(hipErrorOutOfMemory, "hipMalloc hdri", __FILE__, __LINE__); break; }
+                if (hipMemcpy(d_img, scene->hdri->data(), scene->hdri->size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) { rc = 1; set_error("pt_scene_commit: environment map upload failed"); break; }
                 if (hipMalloc(&d_quads, (size_t)(n_texels * 64)) != hipSuccess) { rc = hip_fail(hipErrorOutOfMemory, "hipMalloc hdri records", __FILE__, __LINE__); break; }
                 scene->allocs.push_back(d_quads);
                 rc = launch_hdri_quads(static_cast<const float *>(d_img), scene->hdri_w, scene->hdri_h, static_cast<float *>(d_quads), nullptr);
@@ -527,7 +727,7 @@ int pt_scene_commit(pt_scene *scene) {
             if (rc) return 1;
             d.hdri_quads = static_cast<const float *>(d_quads);
             scene->bytes_hdri += n_texels * 64;
-        } else if (upload_vec(scene, scene->hdri, &d.hdri, &scene->bytes_hdri)) {
+        } else if (upload_vec(scene, *scene->hdri, &d.hdri, &scene->bytes_hdri)) {
             return 1;
         }
     }
@@ -558,8 +758,8 @@ int pt_scene_commit(pt_scene *scene) {
      * included, so waiting costs it less and its optimum lies higher (measured: 48 / 40 against 40 / 12) */
     if (!scene->quorum_fixed) {
         bool textured = false;
-        for (const MaterialHost &m : scene->materials)
-            for (int k = 0; k < 4; k++) textured = textured || !m.maps[k].empty();
+        for (const auto &m : scene->materials)
+            for (int k = 0; k < 4; k++) textured = textured || !m->maps[k].empty();
         /* an octree so deep that its LDS stacks leave room for three waves per SIMD only: fewer waves cover the round's
          * fetches, so it should come less often (20 M triangles at depth 9, quorum x leaf quota: 48 x 12 is +2 % on 40 x 20) */
         const bool few_waves = scene->heavy && render_workgroups_per_cu(max_depth, true) < 4;
@@ -708,7 +908,7 @@ namespace {
 /* fills everything of the launch parameters that follows from the camera and the sample range; returns the bytes of
  * slice partials the launch needs in *need */
 int plan_render(pt_scene *scene, const pt_camera *camera, uint32_t seed, int sample_begin, int sample_end, int n_split,
-                RenderParams &p, size_t *need) {
+                RenderParams &p, size_t *need, int tile_rank = 0, int tile_ranks = 1) {
     memset(&p, 0, sizeof p);
     p.sc = scene->dev;
     p.cam = *camera;
@@ -729,7 +929,11 @@ int plan_render(pt_scene *scene, const pt_camera *camera, uint32_t seed, int sam
         /* a lane counts the samples of its slice down in 16 bits */
         if (p.slice_s1[k] - p.slice_s0[k] > 0xFFFF) PT_FAIL("pt_render_accumulate: more than 65535 samples per slice (split the sample range over several calls)");
     }
-    const uint64_t n_items = (uint64_t)p.mtiles_x * p.mtiles_y * 64 * n_slices;
+    p.tile_first = (uint32_t)tile_rank;
+    p.tile_stride = (uint32_t)tile_ranks;
+    const uint64_t n_tiles = (uint64_t)p.mtiles_x * p.mtiles_y * 64;
+    const uint64_t my_tiles = n_tiles > (uint64_t)tile_rank ? (n_tiles - (uint64_t)tile_rank + (uint64_t)tile_ranks - 1) / (uint64_t)tile_ranks : 0;
+    const uint64_t n_items = my_tiles * n_slices;
     if (n_items >= 0xFFFF0000ull) PT_FAIL("pt_render_accumulate: too many work items");
     p.n_items = (uint32_t)n_items;
     const int64_t n_pixels = (int64_t)camera->res_x * camera->res_y;
@@ -772,7 +976,13 @@ int ensure_events(pt_scene *scene) {
 
 int pt_render_accumulate(pt_scene *scene, const pt_camera *camera, uint32_t seed, int sample_begin, int sample_end,
                          int n_split, float *d_split, pt_counters *counters, void *stream_) {
+    return pt_render_accumulate_tiles(scene, camera, seed, sample_begin, sample_end, n_split, d_split, 0, 1, counters, stream_);
+}
+
+int pt_render_accumulate_tiles(pt_scene *scene, const pt_camera *camera, uint32_t seed, int sample_begin, int sample_end,
+                               int n_split, float *d_split, int tile_rank, int tile_ranks, pt_counters *counters, void *stream_) {
     if (check_render_args("pt_render_accumulate", scene, camera, sample_begin, sample_end, n_split, d_split)) return 1;
+    if (tile_ranks < 1 || tile_rank < 0 || tile_rank >= tile_ranks) PT_FAIL("pt_render_accumulate_tiles: need 0 <= tile_rank < tile_ranks");
     if (sample_end == sample_begin) {
         if (counters) memset(counters, 0, sizeof *counters);
         return 0;
@@ -783,7 +993,11 @@ int pt_render_accumulate(pt_scene *scene, const pt_camera *camera, uint32_t seed
     const int64_t n_pixels = (int64_t)camera->res_x * camera->res_y;
     RenderParams p;
     size_t need = 0;
-    if (plan_render(scene, camera, seed, sample_begin, sample_end, n_split, p, &need)) return 1;
+    if (plan_render(scene, camera, seed, sample_begin, sample_end, n_split, p, &need, tile_rank, tile_ranks)) return 1;
+    if (p.n_items == 0) {
+        if (counters) memset(counters, 0, sizeof *counters);
+        return 0;
+    }
     if (scene->partials.bytes < need) {
         /* the previous launch may still read the old workspace */
         PT_HIP(hipStreamSynchronize(stream));
@@ -796,6 +1010,8 @@ int pt_render_accumulate(pt_scene *scene, const pt_camera *camera, uint32_t seed
     p.tickets = scene->d_tickets;
     p.stats = counters ? scene->d_stats : nullptr;
     PT_HIP(hipMemsetAsync(scene->d_tickets, 0, (kMaxQueues + 1) * sizeof(uint32_t), stream));
+    /* a share of the tiles leaves the other tiles' partials unwritten: they must read as zero in the compounding kernel */
+    if (tile_ranks > 1) PT_HIP(hipMemsetAsync(p.partials, 0, need, stream));
     if (counters) PT_HIP(hipMemsetAsync(scene->d_stats, 0, 16 * sizeof(unsigned long long), stream));
     if (scene->profiling) {
         if (ensure_events(scene)) return 1;
@@ -868,7 +1084,7 @@ int pt_render_accumulate_noalloc(pt_scene *scene, const pt_camera *camera, uint3
             q.n_slices = g;
             q.div_slices = make_udiv((uint32_t)g);
             for (int k = 0; k < g; k++) slice_range(p.plan, z * sps + j + k, q.slice_s0[k], q.slice_s1[k]);
-            q.n_items = (uint32_t)((uint64_t)p.mtiles_x * p.mtiles_y * 64 * g);
+            q.n_items = (uint32_t)((uint64_t)p.mtiles_x * p.mtiles_y * 64 * g);      /* (every tile: tile_first 0, tile_stride 1) */
             q.partials = parts;
             if (launch_zero_words(q.tickets, kMaxQueues + 1, stream)) return 1;
             if (launch_render(q, scene->n_cu, kMaxQueues, scene->heavy, stream)) return 1;

@@ -88,7 +88,9 @@ struct RenderParams {
                                   * fewer): slice k of the launch takes samples [slice_s0[k], slice_s1[k]) and writes partial image k */
     int tiles_x, tiles_y;        /* 8x8-pixel tiles covering the image */
     int mtiles_x, mtiles_y;      /* 8x8-tile macro tiles covering the tiles */
-    uint32_t n_items;            /* mtiles_x * mtiles_y * 64 tiles * slices */
+    uint32_t tile_first, tile_stride;   /* the launch renders tiles tile_first, tile_first + tile_stride, ... of the macro-tile sequence
+                                         * (0, 1: every tile; r, n: the r-th of n interleaved shares) */
+    uint32_t n_items;            /* (this launch's tiles of the mtiles_x * mtiles_y * 64) * slices */
     uint32_t n_queues;           /* == gridDim.x: every workgroup owns one contiguous range of the items */
     uint32_t items_per_queue;    /* ceil(n_items / n_queues): queue q owns items [q * per, (q + 1) * per) cut at n_items */
     uint32_t *tickets;           /* n_queues cursors, then the number of exhausted queues; zeroed before the launch */

@@ -619,8 +619,9 @@ __global__ void __launch_bounds__(kBlock, WAVES) render_kernel(RenderParams P) {
                     probes = (uint32_t)__builtin_amdgcn_readfirstlane((int)probes);
                     if (id == 0xFFFFFFFFu) { exhausted = true; break; }
                     /* item -> (tile in macro-tile order, slice) */
-                    const uint32_t tseq = udiv(id, P.div_slices);
-                    pool_slice = (int)(id - tseq * (uint32_t)n_slices);
+                    const uint32_t tidx = udiv(id, P.div_slices);
+                    pool_slice = (int)(id - tidx * (uint32_t)n_slices);
+                    const uint32_t tseq = tidx * P.tile_stride + P.tile_first;      /* this launch's share of the tiles, interleaved */
                     const uint32_t mt = tseq >> 6, lt = tseq & 63u;
                     const uint32_t mty = udiv(mt, P.div_mtiles_x), mtx = mt - mty * (uint32_t)P.mtiles_x;
                     pool_px0 = (int)((mtx * 8u + (lt & 7u)) * 8u);

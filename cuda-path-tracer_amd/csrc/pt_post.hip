@@ -361,9 +361,21 @@ int pt_reduce_sum(int dst_device, float *d_dst, int n_src, const int *src_device
     float *d_tmp = nullptr;
     PT_HIP(hipMalloc((void **)&d_tmp, bytes));
     int rc = 0;
+    /* peer access from the destination to every other source GPU that allows it: copies between peers then go over the
+     * GPUs' links; without it (or where the two GPUs cannot be peers) the runtime stages the copy through host memory.
+     * "Already enabled" is fine; any other refusal only costs speed. */
+    for (int i = 0; i < n_src; i++) {
+        if (src_devices[i] == dst_device) continue;
+        int can = 0;
+        if (hipDeviceCanAccessPeer(&can, dst_device, src_devices[i]) == hipSuccess && can) {
+            const hipError_t pe = hipDeviceEnablePeerAccess(src_devices[i], 0);
+            if (pe != hipSuccess) (void)hipGetLastError();      /* hipErrorPeerAccessAlreadyEnabled, or not permitted: copy staged */
+        } else {
+            (void)hipGetLastError();
+        }
+    }
     for (int i = 0; i < n_src && !rc; i++) {
-        /* the source devices have finished writing (the caller synchronised them); the copy crosses xGMI
-         * directly when the two GPUs are peers, and goes through the host otherwise */
+        /* the source devices have finished writing (the caller synchronised them) */
         hipError_t e = src_devices[i] == dst_device ? hipMemcpyAsync(d_tmp, d_src[i], bytes, hipMemcpyDeviceToDevice, nullptr)
                                                     : hipMemcpyPeerAsync(d_tmp, dst_device, d_src[i], src_devices[i], bytes, nullptr);
         if (e != hipSuccess) { rc = hip_fail(e, "peer copy", __FILE__, __LINE__); break; }

@@ -589,18 +589,23 @@ pt_camera to_abi(const Camera &camera) {
 
 /* one GPU's share of a render: samples [begin, end) of every pixel into fresh split buffers, compounded into
  * *d_sum_out (device memory on `dev`, owned by the caller afterwards) */
-void render_share(pt_scene *scene, int dev, const pt_camera &cam, unsigned seed, int begin, int end, int n_split, void **d_sum_out) {
+/* returns 0, or the failed call's status with its message in `err` (the C ABI's error string is per thread: a worker
+ * thread reports through the string, and the caller exits after joining every thread) */
+int render_share(pt_scene *scene, int dev, const pt_camera &cam, unsigned seed, int begin, int end, int n_split, void **d_sum_out, std::string &err) {
     const int64_t n_pixels = (int64_t)cam.res_x * cam.res_y;
     const size_t img_bytes = (size_t)n_pixels * sizeof(vec3);
     void *d_split = nullptr, *d_sum = nullptr;
-    PT_CHECK(pt_malloc(dev, img_bytes * n_split, &d_split));
-    PT_CHECK(pt_malloc(dev, img_bytes, &d_sum));
-    PT_CHECK(pt_memset(dev, d_split, 0, img_bytes * n_split, nullptr));    /* the reference never clears its buffer */
-    PT_CHECK(pt_render_accumulate(scene, &cam, seed, begin, end, n_split, (float *)d_split, nullptr, nullptr));
-    PT_CHECK(pt_compound_buffers(dev, (const float *)d_split, (float *)d_sum, n_pixels, n_split, nullptr));
-    PT_CHECK(pt_stream_synchronize(dev, nullptr));
-    PT_CHECK(pt_free(dev, d_split));
+    int rc = 0;
+#define PT_TRY(call) if (!rc && (rc = (call)) != 0) err = std::string(#call) + " failed: " + pt_last_error()
+    PT_TRY(pt_malloc(dev, img_bytes * n_split, &d_split));
+    PT_TRY(pt_malloc(dev, img_bytes, &d_sum));
+    PT_TRY(pt_memset(dev, d_split, 0, img_bytes * n_split, nullptr));    /* the reference never clears its buffer */
+    PT_TRY(pt_render_accumulate(scene, &cam, seed, begin, end, n_split, (float *)d_split, nullptr, nullptr));
+    PT_TRY(pt_compound_buffers(dev, (const float *)d_split, (float *)d_sum, n_pixels, n_split, nullptr));
+    PT_TRY(pt_stream_synchronize(dev, nullptr));
+    if (d_split) (void)pt_free(dev, d_split);
     *d_sum_out = d_sum;
+    return rc;
 }
 
 }  // namespace
@@ -630,22 +635,37 @@ Image Renderer::render(const Camera &camera, Scene &scene) {
 
     std::cout << "start render" << std::endl;
     std::vector<void *> d_sums(n_dev, nullptr);
+    std::vector<std::string> errors(n_dev);
+    std::vector<int> status(n_dev, 0);
     if (handles[0]) {
-        render_share(handles[0], root, cam, this->seed, 0, (int)spp, n_split, &d_sums[0]);
+        status[0] = render_share(handles[0], root, cam, this->seed, 0, (int)spp, n_split, &d_sums[0], errors[0]);
     } else {
-        /* one host thread per GPU: copy the scene there, render the rank's contiguous share of the samples */
+        /* The scene is flattened and its octrees are built ONCE, for the first GPU; every other GPU gets a clone that
+         * shares that host-side description (pt_scene_clone) and only uploads it.  One host thread per GPU: upload,
+         * render the GPU's contiguous share of the samples.  A thread that fails records why; nothing exits while
+         * other threads are inside the runtime. */
+        handles[0] = scene.build_on(devs[0]);
         std::vector<std::thread> workers;
         for (int r = 0; r < n_dev; r++)
             workers.emplace_back([&, r]() {
-                handles[r] = scene.build_on(devs[r]);
+                if (r > 0) {
+                    status[r] = pt_scene_clone(handles[0], devs[r], &handles[r]);
+                    if (!status[r]) status[r] = pt_scene_commit(handles[r]);
+                    if (status[r]) { errors[r] = std::string("copying the scene to device failed: ") + pt_last_error(); return; }
+                }
                 const int begin = (int)(((long long)spp * r) / n_dev), end = (int)(((long long)spp * (r + 1)) / n_dev);
-                render_share(handles[r], devs[r], cam, this->seed, begin, end, n_split, &d_sums[r]);
+                status[r] = render_share(handles[r], devs[r], cam, this->seed, begin, end, n_split, &d_sums[r], errors[r]);
             });
         for (std::thread &w : workers) w.join();
-        /* root += the other GPUs' sums, in list order (peer copies; fixed order: reproducible bits) */
-        if (n_dev > 1)
-            PT_CHECK(pt_reduce_sum(root, (float *)d_sums[0], n_dev - 1, devs.data() + 1, (const float *const *)(d_sums.data() + 1), n_pixels * 3));
     }
+    for (int r = 0; r < n_dev; r++)
+        if (status[r]) {
+            fprintf(stderr, "ptamd: device %d: %s\n", devs[r], errors[r].c_str());
+            exit(status[r]);
+        }
+    /* root += the other GPUs' sums, in list order (fixed order: reproducible bits) */
+    if (n_dev > 1)
+        PT_CHECK(pt_reduce_sum(root, (float *)d_sums[0], n_dev - 1, devs.data() + 1, (const float *const *)(d_sums.data() + 1), n_pixels * 3));
 
     void *d_out = nullptr;
     PT_CHECK(pt_malloc(root, img_bytes, &d_out));

@@ -18,6 +18,7 @@
 #include <vector>
 
 #include "path_tracer.h"
+#include "ptamd.h"
 
 static void put(FILE *f, const void *p, size_t n) {
     if (fwrite(p, 1, n, f) != n) { perror("fwrite"); exit(2); }
@@ -111,6 +112,9 @@ static int cmd_teapot(int argc, char **argv) {
     put(f, img.buf.data(), img.buf.size() * sizeof(vec3));
     fclose(f);
     save_ppm(std::string(argv[7]) + ".ppm", img);
+    uint64_t builds = 0;
+    pt_octree_builds(&builds);
+    printf("octrees built by the library: %llu\n", (unsigned long long)builds);
     return 0;
 }
 

@@ -55,8 +55,8 @@ HIT_DTYPE = np.dtype([("entity", "<i4"), ("triangle", "<i4"), ("t", "<f4"), ("bu
 # every symbol include/ptamd.h declares
 ABI_SYMBOLS = [
     "pt_last_error", "pt_device_count", "pt_device_name", "pt_scene_create", "pt_scene_destroy", "pt_scene_add_material",
-    "pt_scene_add_mesh", "pt_scene_add_sphere", "pt_scene_set_hdri", "pt_scene_commit", "pt_scene_octree_info",
-    "pt_scene_octree_dump", "pt_scene_device_bytes", "pt_trace_rays", "pt_camera_rays", "pt_sample_hdri", "pt_sample_material", "pt_box_intersects_triangle", "pt_child_tables", "pt_render_accumulate",
+    "pt_scene_add_mesh", "pt_scene_add_sphere", "pt_scene_set_hdri", "pt_scene_commit", "pt_scene_clone", "pt_scene_save", "pt_scene_load", "pt_octree_builds", "pt_scene_octree_info",
+    "pt_scene_octree_dump", "pt_scene_device_bytes", "pt_trace_rays", "pt_camera_rays", "pt_sample_hdri", "pt_sample_material", "pt_box_intersects_triangle", "pt_child_tables", "pt_render_accumulate", "pt_render_accumulate_tiles",
     "pt_render_accumulate_noalloc", "pt_noalloc_max_partial_bytes", "pt_scene_set_launch", "pt_scene_get_launch", "pt_scene_render_residency",
     "pt_scene_set_profiling", "pt_scene_schedule_counters", "pt_scene_last_render_kernel_ms", "pt_compound_buffers", "pt_reduce_sum", "pt_apply_filter", "pt_make_gaussian", "pt_make_mean", "pt_normalize_image", "pt_apply_threshold",
     "pt_image_add", "pt_apply_aces", "pt_gamma_correct", "pt_post_chain", "pt_malloc", "pt_free", "pt_memset", "pt_upload",
@@ -84,6 +84,10 @@ def lib():
         L.pt_scene_add_sphere.argtypes = [vp, C.POINTER(C.c_float), f32, i32, C.POINTER(C.c_int)]
         L.pt_scene_set_hdri.argtypes = [vp, vp, i32, i32, f32, f32, f32, i32]
         L.pt_scene_commit.argtypes = [vp]
+        L.pt_scene_clone.argtypes = [vp, i32, C.POINTER(vp)]
+        L.pt_scene_save.argtypes = [vp, C.c_char_p]
+        L.pt_scene_load.argtypes = [i32, C.c_char_p, C.POINTER(vp)]
+        L.pt_octree_builds.argtypes = [C.POINTER(C.c_uint64)]
         L.pt_scene_octree_info.argtypes = [vp, i32, C.POINTER(OctreeInfo)]
         L.pt_scene_octree_dump.argtypes = [vp, i32, vp, i64, C.POINTER(C.c_int64)]
         L.pt_scene_device_bytes.argtypes = [vp] + [C.POINTER(C.c_uint64)] * 5
@@ -94,6 +98,7 @@ def lib():
         L.pt_box_intersects_triangle.argtypes = [vp, vp, vp, vp, vp, i32, C.POINTER(C.c_int)]
         L.pt_child_tables.argtypes = [vp, vp]
         L.pt_render_accumulate.argtypes = [vp, C.POINTER(Camera), u32, i32, i32, i32, vp, vp, vp]
+        L.pt_render_accumulate_tiles.argtypes = [vp, C.POINTER(Camera), u32, i32, i32, i32, vp, i32, i32, vp, vp]
         L.pt_render_accumulate_noalloc.argtypes = [vp, C.POINTER(Camera), u32, i32, i32, i32, vp, vp]
         L.pt_noalloc_max_partial_bytes.argtypes = []
         L.pt_noalloc_max_partial_bytes.restype = C.c_size_t
@@ -209,13 +214,24 @@ class DeviceBuffer:
 class Scene:
     """Mirror of the reference's Scene/Entity/Material host objects over the C ABI."""
 
-    def __init__(self, device=0):
+    def __init__(self, device=0, _handle=None):
         self.L = lib()
         self.device = device
-        h = C.c_void_p()
-        check(self.L.pt_scene_create(device, C.byref(h)))
-        self.h = h
+        if _handle is None:
+            _handle = C.c_void_p()
+            check(self.L.pt_scene_create(device, C.byref(_handle)))
+        self.h = _handle
         self._keep = []
+
+    def clone(self, device):
+        """An uncommitted scene for another GPU that shares this one's host-side description (built octrees included)."""
+        h = C.c_void_p()
+        check(self.L.pt_scene_clone(self.h, device, C.byref(h)))
+        return Scene(device, h)
+
+    def save(self, path):
+        """Writes the host-side description with its built octrees to a file (see load_scene)."""
+        check(self.L.pt_scene_save(self.h, os.fsencode(path)))
 
     def close(self):
         if getattr(self, "h", None):
@@ -317,10 +333,12 @@ class Scene:
         check(self.L.pt_sample_material(self.h, material, uv.ctypes.data, n, a.ctypes.data, s.ctypes.data, sm.ctypes.data, nn.ctypes.data))
         return a, s, sm, nn
 
-    def render_accumulate(self, cam, seed, sample_begin, sample_end, n_split, d_split_ptr, want_counters=False, stream=None):
+    def render_accumulate(self, cam, seed, sample_begin, sample_end, n_split, d_split_ptr, want_counters=False, stream=None,
+                          tiles=(0, 1)):
+        """tiles = (rank, ranks): only the rank-th of `ranks` interleaved shares of the 8x8-pixel tiles (pt_render_accumulate_tiles)."""
         cnt = Counters()
-        check(self.L.pt_render_accumulate(self.h, C.byref(cam), seed, sample_begin, sample_end, n_split, d_split_ptr,
-                                          C.byref(cnt) if want_counters else None, stream))
+        check(self.L.pt_render_accumulate_tiles(self.h, C.byref(cam), seed, sample_begin, sample_end, n_split, d_split_ptr,
+                                                int(tiles[0]), int(tiles[1]), C.byref(cnt) if want_counters else None, stream))
         return cnt.as_dict() if want_counters else None
 
     def render_accumulate_noalloc(self, cam, seed, sample_begin, sample_end, n_split, d_split_ptr, stream=None):
@@ -357,6 +375,23 @@ class Scene:
         ms = C.c_float(0)
         check(self.L.pt_scene_last_render_kernel_ms(self.h, C.byref(ms)))
         return float(ms.value)
+
+
+def load_scene(path, device=0, commit=True):
+    """A Scene from a file written by Scene.save: nothing is rebuilt."""
+    h = C.c_void_p()
+    check(lib().pt_scene_load(device, os.fsencode(path), C.byref(h)))
+    sc = Scene(device, h)
+    if commit:
+        sc.commit()
+    return sc
+
+
+def octree_builds():
+    """Octrees this process has built since the library was loaded."""
+    n = C.c_uint64(0)
+    check(lib().pt_octree_builds(C.byref(n)))
+    return int(n.value)
 
 
 def scene_from_description(desc, device=0, commit=True):
@@ -404,13 +439,14 @@ def make_mean(size):
     return t
 
 
-def render_image(scene, cam, spp, seed=1337, n_split=4, sample_begin=0, device=0, want_counters=False):
-    """Convenience: renders sample_begin..sample_begin+spp-1 and returns the un-normalised HxWx3 sum (host)."""
+def render_image(scene, cam, spp, seed=1337, n_split=4, sample_begin=0, device=0, want_counters=False, tiles=(0, 1)):
+    """Convenience: renders sample_begin..sample_begin+spp-1 (of the tile share `tiles`, default every tile) and returns the
+    un-normalised HxWx3 sum (host)."""
     n_pixels = cam.res_x * cam.res_y
     split = DeviceBuffer(device, n_split * n_pixels * 12)
     out = DeviceBuffer(device, n_pixels * 12)
     split.zero()
-    cnt = scene.render_accumulate(cam, seed, sample_begin, sample_begin + spp, n_split, split.ptr, want_counters)
+    cnt = scene.render_accumulate(cam, seed, sample_begin, sample_begin + spp, n_split, split.ptr, want_counters, tiles=tiles)
     check(lib().pt_compound_buffers(device, split.ptr, out.ptr, n_pixels, n_split, None))
     img = out.download((cam.res_y, cam.res_x, 3))
     split.free()

@@ -1,5 +1,5 @@
 """Multi-GPU rendering: one process per GPU, scene replicated, the sample range of every pixel
-sharded over ranks, per-rank accumulation buffers combined by one sum-reduce (RCCL over xGMI via
+sharded over ranks (or, for renders of few samples, the image's tiles: shard_work), per-rank accumulation buffers combined by one sum-reduce (RCCL over xGMI via
 torch.distributed's "nccl" backend; "gloo" on CPU for tests).
 
 The reference is single-GPU; its own decomposition gives n_blocks_per_tile x n_split_buffers = 32
@@ -18,6 +18,21 @@ def shard_samples(n_samples, rank, world_size, sample_begin=0):
     b = sample_begin + (n_samples * rank) // world_size
     e = sample_begin + (n_samples * (rank + 1)) // world_size
     return b, e
+
+
+MIN_SAMPLES_PER_RANK = 8     # one sample slice of the render kernel's work items
+
+
+def shard_work(n_samples, rank, world_size, sample_begin=0):
+    """What `rank` renders: ((sample_begin, sample_end), (tile_rank, tile_ranks)).  With at least MIN_SAMPLES_PER_RANK
+    samples per rank the sample range is cut (every rank traces every pixel: identical cache behaviour, perfect balance);
+    with fewer, every rank renders ALL samples of its interleaved share of the 8x8-pixel tiles -- the tile axis of the
+    reference's grid (src/renderer.cu:219-223) -- so that a rank's launch is not shorter than the kernel's start-up."""
+    if world_size < 1 or not (0 <= rank < world_size):
+        raise ValueError("bad rank / world size")
+    if n_samples >= MIN_SAMPLES_PER_RANK * world_size:
+        return shard_samples(n_samples, rank, world_size, sample_begin), (0, 1)
+    return (sample_begin, sample_begin + n_samples), (rank, world_size)
 
 
 def effective_spp(spp, n_split_buffers=4, n_blocks_per_tile=8):

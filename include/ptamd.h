@@ -124,6 +124,21 @@ int pt_scene_set_hdri(pt_scene *scene, const float *rgb, int w, int h, float exp
  * more) fix them.  Limits: 2^29 octree nodes and
  * 4 GiB of triangle pairs per scene. */
 int pt_scene_commit(pt_scene *scene);
+/* ---- one scene, several GPUs (no counterpart in the reference, which builds and uploads one scene in one process for
+ * device 0: src/main.cu:22-46, src/renderer.cu:201).  A scene's octrees are built when its meshes are added
+ * (Entity::construct_octree, src/entity.cu:167-170); these entry points hand a built scene on so that a node builds it once:
+ * pt_scene_clone: a new uncommitted scene for `device` (or a host-only one, device < 0) that SHARES the source's host-side
+ *   description -- materials, maps, meshes, built octrees, environment map -- without copying or rebuilding anything, and
+ *   takes over its launch choices; commit it to upload.  For one process driving several GPUs.  Either scene may be
+ *   destroyed first.
+ * pt_scene_save / pt_scene_load: the same description, octrees included, to and from a file (native byte order; put it
+ *   on a RAM-backed file system such as /dev/shm): one process per GPU, the first builds and saves, the others load.  A
+ *   loaded scene is uncommitted; it equals the saved one node for node (pt_scene_octree_dump).
+ * pt_octree_builds: number of octrees this process has built since the library was loaded. */
+int pt_scene_clone(pt_scene *src, int device, pt_scene **out);
+int pt_scene_save(pt_scene *scene, const char *path);
+int pt_scene_load(int device, const char *path, pt_scene **out);
+int pt_octree_builds(uint64_t *count);
 int pt_scene_octree_info(pt_scene *scene, int entity, pt_octree_info *info);
 /* canonical pre-order dump of the flattened octree: per node {depth, slot, child mask, n_tris,
  * tris...}; returns the number of int32 words needed in *n_words (out may be NULL). */
@@ -180,6 +195,14 @@ int pt_child_tables(uint8_t *set_out, uint8_t *mir_out);
 int pt_render_accumulate(pt_scene *scene, const pt_camera *camera, uint32_t seed,
                          int sample_begin, int sample_end, int n_split, float *d_split,
                          pt_counters *counters, void *stream);
+/* pt_render_accumulate for one of tile_ranks interleaved shares of the image's 8x8-pixel tiles (share tile_rank takes every
+ * tile_ranks-th tile of the tile sequence, so all shares see the same mix of scene content); pixels of other tiles are
+ * left unchanged.  The reference's own grid has this tile axis (src/renderer.cu:219-223); it is the axis to shard over
+ * GPUs when a render has too few samples per pixel to give every GPU a worthwhile slice of them.  Every sample of a pixel
+ * is rendered by one share, with the summation order of the unsharded call: the shares' images add up to its bits. */
+int pt_render_accumulate_tiles(pt_scene *scene, const pt_camera *camera, uint32_t seed,
+                               int sample_begin, int sample_end, int n_split, float *d_split,
+                               int tile_rank, int tile_ranks, pt_counters *counters, void *stream);
 /* Variant of pt_render_accumulate that allocates nothing.  It has no counterpart in the reference; it is
  * for callers that cannot call hipMalloc: code under HIP graph capture, tight serving loops, harnesses
  * that forbid allocation.  Same arguments, same kernels and the same split-buffer bits as ONE
@@ -230,8 +253,9 @@ int pt_compound_buffers(int device, const float *d_split, float *d_out, int64_t 
 
 /* ---- multi-GPU inside one process (no counterpart in the reference, which renders on device 0 only,
  * src/renderer.cu:209-216): d_dst (on dst_device) += d_src[0] + d_src[1] + ... in THAT order, each n_floats
- * floats on device src_devices[i].  Sources reach dst_device by peer copies (xGMI between peers) into a
- * staging buffer and are added one after the other, so the result does not depend on timing.  Blocking: all
+ * floats on device src_devices[i].  Sources reach dst_device by peer copies into a staging buffer (peer access is
+ * enabled where the two GPUs allow it, so that the copy uses the links between them; otherwise the runtime stages it
+ * through host memory) and are added one after the other, so the result does not depend on timing.  Blocking: all
  * work on the source buffers must have completed before the call; the sum is complete when it returns.
  * One process per GPU setups use a collective instead (torch.distributed / RCCL reduce, see bench.py). */
 int pt_reduce_sum(int dst_device, float *d_dst, int n_src, const int *src_devices,

@@ -61,3 +61,23 @@ def test_two_rank_sharded_render_equals_single(tmp_path, oracle, scenes):
     assert np.allclose(got, want, rtol=1e-5, atol=1e-6)
     half, _ = sc.render(cam, 1337, 0, 4)
     assert not np.allclose(got, half, rtol=1e-3)
+
+
+def test_shard_work_picks_samples_or_tiles():
+    sys.path.insert(0, os.path.join(REPO, "cuda-path-tracer_amd", "python"))
+    from ptamd import dist as ptdist
+
+    # enough samples per rank: contiguous sample ranges that tile [0, spp), every tile on every rank
+    for spp, world in ((2048, 8), (64, 8), (32, 4), (33, 3)):
+        got = [ptdist.shard_work(spp, r, world) for r in range(world)]
+        assert all(t == (0, 1) for _, t in got)
+        assert got[0][0][0] == 0 and got[-1][0][1] == spp
+        assert all(got[r][0][1] == got[r + 1][0][0] for r in range(world - 1))
+        assert all(e - b >= 8 for (b, e), _ in got)
+    # fewer than 8 samples per rank: all samples, interleaved tile shares
+    for spp, world in ((32, 8), (32, 5), (8, 2)):
+        got = [ptdist.shard_work(spp, r, world, sample_begin=3) for r in range(world)]
+        assert all(s == (3, 3 + spp) for s, _ in got)
+        assert [t for _, t in got] == [(r, world) for r in range(world)]
+    with pytest.raises(ValueError):
+        ptdist.shard_work(32, 2, 2)

@@ -237,6 +237,8 @@ def test_renderer_depth_nine_and_two_device_render(pt, scenes, tmp_path):
         ldr = np.frombuffer(raw, np.float32, n, 12 + 4 * n).reshape(h, w, 3)
         assert np.array_equal(hdr_sum, expect), devices
         assert np.array_equal(ldr, pt.post_chain_host(expect, spp)), devices
+        # the teapot's octree is built once however many GPUs render (the second device gets a clone of the built scene)
+        assert "octrees built by the library: 1\n" in r.stdout, r.stdout
         if devices:
             assert r.stdout.count("Device 0") == 2
 

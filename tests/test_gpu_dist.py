@@ -59,8 +59,30 @@ def test_bench_two_ranks_on_one_gpu(tmp_path):
     assert d["counters"]["paths"] == 96 * 56 * 64          # both ranks' counters, summed
     assert d["value"] > 0 and d["ms_per_step"] > 0
     assert d["roofline"]["bound"] == "valu-issue" and d["roofline"]["kernel_ms"] > 0
+    # the scene is built once per node: rank 0 builds the teapot's octree, rank 1 loads the built scene
+    assert d["scene_by_rank"]["octree_builds"] == [1, 0] and len(d["scene_by_rank"]["build_upload_s"]) == 2
+    assert d["config"]["parallelism"] == "sample-shard x2"
     one = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--workload", "teapot", "--res", "96x56", "--spp", "64",
                           "--steps", "1", "--warmup", "0", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=300)
     assert one.returncode == 0, one.stderr[-2000:]
     d1 = json.loads([ln for ln in one.stdout.splitlines() if ln.startswith("{")][0])
     assert d1["n_gpus"] == 1 and d1["counters"] == d["counters"]
+
+
+def test_bench_shards_tiles_when_samples_are_few(tmp_path):
+    """Five ranks on a 32-spp render (fewer than 8 samples per rank): bench.py shards the image's tiles instead of the
+    samples; the ranks' counters add up to the single-process run's, one octree is built in all."""
+    import json
+
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    common = ["--workload", "teapot", "--res", "96x56", "--spp", "32", "--steps", "1", "--warmup", "0", "--no-cpu-baseline"]
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "5", "--backend", "gloo"] + common, env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    assert d["n_gpus"] == 5 and d["config"]["parallelism"] == "tile-shard x5" and d["config"]["samples_per_rank"] == 32
+    assert d["scene_by_rank"]["octree_builds"] == [1, 0, 0, 0, 0]
+    one = subprocess.run([sys.executable, os.path.join(REPO, "bench.py")] + common, env=env, capture_output=True, text=True, timeout=300)
+    assert one.returncode == 0, one.stderr[-2000:]
+    d1 = json.loads([ln for ln in one.stdout.splitlines() if ln.startswith("{")][0])
+    assert d1["counters"] == d["counters"] and d1["counters"]["paths"] == 96 * 56 * 32

@@ -98,6 +98,32 @@ def test_simulated_ranks_equal_single_gpu(pt, scenes):
     g.close()
 
 
+def test_simulated_tile_ranks_add_up_to_the_single_gpu_bits(pt, scenes):
+    """Renders of few samples are sharded over GPUs by interleaved 8x8-pixel tiles (pt_render_accumulate_tiles): every
+    rank renders all samples of its tiles with the summation order of the unsharded call, so the ranks' images add up
+    to the single-GPU image bit for bit, and their work counters to its counters.  Ranks simulated on one GPU."""
+    desc = scenes.hcandersen_scene(res=(100, 52), n_tris=6000, tex_res=128, hdri_res=(128, 64))       # 13 x 7 tiles, ragged edges
+    g, cam = pt.scene_from_description(desc)
+    whole, cnt_whole = pt.render_image(g, cam, 12, seed=7, want_counters=True)
+    assert whole.max() > 0
+    for world in (2, 3, 8, 200):
+        total = np.zeros_like(whole)
+        cnt = dict.fromkeys(cnt_whole, 0)
+        covered = np.zeros(whole.shape[:2], np.int32)
+        for r in range(world):
+            img, c = pt.render_image(g, cam, 12, seed=7, want_counters=True, tiles=(r, world))
+            total += img
+            covered += (img.max(axis=-1) > 0)
+            for k in cnt:
+                cnt[k] += c[k]
+        assert covered.max() == 1, world                       # no pixel rendered by two ranks
+        assert np.array_equal(total.view(np.uint32), whole.view(np.uint32)), world
+        assert cnt == cnt_whole, world
+    with pytest.raises(pt.PtError, match="tile_rank"):
+        pt.render_image(g, cam, 4, tiles=(3, 3))
+    g.close()
+
+
 def test_both_kernel_builds_give_identical_images(pt, scenes, monkeypatch):
     """The render kernel exists in two builds (chosen per scene at commit, PTAMD_KERNEL overrides): the
     light one tests every lane's triangle runs lane by lane, the heavy one hands the waiting runs of a

@@ -207,3 +207,48 @@ def test_child_set_table_equals_stepping_the_reference_loop(pt):
     assert np.array_equal(tab[key].astype(np.uint32), stepped)
     sizes = np.bincount([bin(int(x)).count("1") for x in stepped], minlength=5)
     assert sizes[2:].min() > 5000 and np.unique(key).size >= 60, (sizes, np.unique(key).size)
+
+
+def test_scene_save_load_and_clone_carry_the_built_octrees(pt, scenes, teapot, tmp_path):
+    """A scene built once can be handed to other GPUs of the node without rebuilding anything: as a clone inside one
+    process, through a file between processes.  Same trees node for node, no octree build counted; damaged files
+    are refused."""
+    pos, tri = teapot
+    sc = pt.Scene(-1)
+    rng = np.random.default_rng(2)
+    maps = dict(albedo=rng.integers(0, 256, (6, 10, 3), dtype=np.uint8), smoothness=rng.integers(0, 256, (3, 5), dtype=np.uint8))
+    m0 = sc.add_material((0.1, 0.2, 0.3), (0.4, 0.5, 0.6), 2.0, 0.7, True, maps)
+    m1 = sc.add_material()
+    e0 = sc.add_mesh(pos, tri, m0, octree_depth=5)
+    sc.add_sphere((1, 2, 3), 4.0, m1)
+    fpos, ftri, _, _ = scenes.load_obj(os.path.join(REPO, "examples", "cornellbox", "floor.obj"))
+    e2 = sc.add_mesh(fpos, ftri, m1, octree_depth=0)
+    sc.set_hdri(rng.random((4, 8, 3), dtype=np.float32), 1.5, 1.2, 0.25, True)
+    built = pt.octree_builds()
+    path = str(tmp_path / "scene.bin")
+    sc.save(path)
+    loaded = pt.load_scene(path, device=-1, commit=False)
+    clone = sc.clone(-1)
+    assert pt.octree_builds() == built
+    for other in (loaded, clone):
+        assert np.array_equal(other.octree_dump(e0), sc.octree_dump(e0))
+        assert other.octree_info(e0)["nodes_per_depth"].tolist() == sc.octree_info(e0)["nodes_per_depth"].tolist()
+        with pytest.raises(pt.PtError, match="no octree"):
+            other.octree_info(e2)
+    # a saved scene saves again to the same bytes
+    path2 = str(tmp_path / "again.bin")
+    loaded.save(path2)
+    data = open(path, "rb").read()
+    assert data == open(path2, "rb").read()
+    sc.close()          # the clone and the loaded scene outlive their source
+    assert clone.octree_info(e0)["n_nodes"] > 0
+    clone.close()
+    loaded.close()
+    # damaged files: truncated, wrong magic, cut inside the header
+    bad = str(tmp_path / "bad.bin")
+    for blob in (data[: len(data) // 2], b"NOTASCENE" + data[9:], data[:8]):
+        open(bad, "wb").write(blob)
+        with pytest.raises(pt.PtError, match="scene file"):
+            pt.load_scene(bad, device=-1, commit=False)
+    with pytest.raises(pt.PtError, match="cannot open"):
+        pt.load_scene(str(tmp_path / "missing.bin"), device=-1, commit=False)
