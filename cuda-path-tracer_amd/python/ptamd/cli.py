@@ -9,7 +9,6 @@ chunks, so a render can be checkpointed and resumed; with several ranks every ra
 of the sample range and rank 0 combines the sums (one RCCL sum-reduce) and writes the image.
 """
 import argparse
-import hashlib
 import os
 import sys
 import time
@@ -36,7 +35,7 @@ def main(argv=None):
     from ptamd import dist as ptdist
     from ptamd import io as ptio
     from ptamd.progressive import Accumulator
-    from ptamd.scenefile import load_scene
+    from ptamd.scenefile import description_hash, load_scene
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -54,9 +53,9 @@ def main(argv=None):
     spp = ptdist.effective_spp(args.spp if args.spp else settings["spp"])
     scene, cam = ptamd.scene_from_description(desc, device=local_rank)
     begin, end = ptdist.shard_samples(spp, rank, world)
-    # a checkpoint is only valid for the scene file it was rendered from: its hash travels in the checkpoint
-    with open(args.scene, "rb") as f:
-        tag = "scene-sha256:" + hashlib.sha256(f.read()).hexdigest()
+    # a checkpoint is only valid for the scene it was rendered from: the hash of the loaded description (the meshes, maps and
+    # environment map the scene file names included, not just the file's own text) travels in the checkpoint
+    tag = "scene-sha256:" + description_hash(desc)
     acc = Accumulator(scene, cam, seed=settings["seed"], device=local_rank, first_sample=begin, tag=tag)
     if args.resume and args.checkpoint and world == 1 and os.path.exists(args.checkpoint):
         acc.load(args.checkpoint, max_samples=end - begin)

@@ -20,6 +20,7 @@ the file has any -- the known flaw of src/entity.cu:58-65 -- else the face-norma
 "computed" always uses the face-normal average, "file" averages the vn each vertex is given by its
 face corners.
 """
+import hashlib
 import json
 import os
 
@@ -221,3 +222,29 @@ def load_scene(path):
     r = doc.get("render", {})
     settings = dict(spp=int(r.get("spp", 1024)), seed=int(r.get("seed", 1337)))
     return dict(name=os.path.basename(path), materials=mats, entities=ents, hdri=hdri, camera=cam), settings
+
+
+def description_hash(desc):
+    """SHA-256 over everything of a scene description that a render depends on -- the arrays as they were loaded (mesh
+    vertices, normals, triangles, uvs, texture maps, environment map), the materials' and entities' scalar fields and the
+    camera -- so that it changes when a mesh, texture or environment file the scene file names is edited, not only when
+    the scene file itself is."""
+    h = hashlib.sha256()
+
+    def put(tag, v):
+        h.update(tag.encode())
+        if isinstance(v, dict):
+            for k in sorted(v):
+                put(tag + "." + str(k), v[k])
+        elif isinstance(v, (list, tuple)) and any(isinstance(x, (dict, np.ndarray, list, tuple)) for x in v):
+            for i, x in enumerate(v):
+                put(f"{tag}[{i}]", x)
+        elif v is None:
+            h.update(b"none")
+        else:
+            a = np.ascontiguousarray(v)
+            h.update(str(a.dtype).encode() + str(a.shape).encode())
+            h.update(a.tobytes())
+
+    put("scene", desc)
+    return h.hexdigest()

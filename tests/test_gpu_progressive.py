@@ -141,3 +141,33 @@ def test_cli_hdr_output_matches_oracle(pt, oracle, tmp_path):
     path.write_text(json.dumps(doc))
     r = subprocess.run(base + ["--checkpoint", str(ck), "--resume"], env=env, capture_output=True, text=True, timeout=120)
     assert r.returncode != 0 and "another scene" in r.stderr
+
+
+def test_cli_checkpoint_is_tied_to_the_files_the_scene_names(tmp_path):
+    """The checkpoint's tag hashes the loaded scene description, so a mesh file edited under an unchanged scene file
+    is noticed on resume (samples of two different scenes are never mixed)."""
+    import shutil
+
+    from test_scenefile import TEAPOT
+
+    obj = tmp_path / "pot.obj"
+    shutil.copy(TEAPOT, obj)
+    doc = _teapot_doc(tmp_path, res=(64, 36))
+    doc["entities"][0]["obj"] = str(obj)
+    doc["render"]["spp"] = 32
+    path = tmp_path / "scene.json"
+    path.write_text(json.dumps(doc))
+    env = dict(os.environ, PYTHONPATH=os.path.join(REPO, "cuda-path-tracer_amd", "python"))
+    ck = tmp_path / "ck.npz"
+    base = [sys.executable, "-m", "ptamd.cli", str(path), "--out", str(tmp_path / "o.ppm"), "--checkpoint", str(ck)]
+    r = subprocess.run(base, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    r = subprocess.run(base + ["--resume"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "resumed at 32" in r.stderr
+    lines = obj.read_text().splitlines()
+    k = next(i for i, ln in enumerate(lines) if ln.startswith("v "))
+    x, y, z = (float(t) for t in lines[k].split()[1:4])
+    lines[k] = f"v {x + 0.5} {y} {z}"
+    obj.write_text("\n".join(lines) + "\n")
+    r = subprocess.run(base + ["--resume"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "another scene" in r.stderr
