@@ -250,7 +250,7 @@ def main():
     value = paths_per_step / (ms_per_step / 1000.0) / 1e6
 
     # ---- roofline of the dominant kernel (this rank's launch of render_kernel)
-    plan_slices = n_split * min(max(1, 64 // n_split), max(1, (-(-(s_end - s_begin) // n_split) + 7) // 8))   # make_slice_plan
+    plan_slices = ptamd.render_slices(cam, s_begin, s_end, n_split)
     k_ms = float(np.mean(kernel_ms)) if kernel_ms else float("nan")
     k_s = k_ms / 1000.0
     workload_name = f"{args.workload} {res[0]}x{res[1]} {spp}spp octree-depth-{meta['depth']}"

@@ -914,11 +914,11 @@ int plan_render(pt_scene *scene, const pt_camera *camera, uint32_t seed, int sam
     p.cam = *camera;
     p.camk = make_cam_consts(*camera);
     p.seed = seed;
-    p.plan = make_slice_plan(sample_begin, sample_end, n_split);
     p.tiles_x = (camera->res_x + 7) / 8;
     p.tiles_y = (camera->res_y + 7) / 8;
     p.mtiles_x = (p.tiles_x + 7) / 8;
     p.mtiles_y = (p.tiles_y + 7) / 8;
+    p.plan = make_slice_plan(sample_begin, sample_end, n_split, (int64_t)p.mtiles_x * p.mtiles_y * 64);
     const int n_slices = p.plan.n_split * p.plan.slices_per_split;
     if (n_slices > kMaxSlices) PT_FAIL("pt_render_accumulate: slice plan exceeds the slice table");
     p.n_slices = n_slices;
@@ -1030,6 +1030,16 @@ int pt_render_accumulate_tiles(pt_scene *scene, const pt_camera *camera, uint32_
         counters_from(h, counters);
         scene->stats_valid = true;
     }
+    return 0;
+}
+
+int pt_render_slices(const pt_camera *camera, int sample_begin, int sample_end, int n_split, int *slices) {
+    if (!camera || !slices) PT_FAIL("pt_render_slices: null argument");
+    if (camera->res_x <= 0 || camera->res_y <= 0 || sample_begin < 0 || sample_end < sample_begin || n_split < 1 || n_split > 64)
+        PT_FAIL("pt_render_slices: bad argument");
+    const int64_t mtx = ((camera->res_x + 7) / 8 + 7) / 8, mty = ((camera->res_y + 7) / 8 + 7) / 8;
+    const SlicePlan pl = make_slice_plan(sample_begin, sample_end, n_split, mtx * mty * 64);
+    *slices = sample_end == sample_begin ? 0 : pl.n_split * pl.slices_per_split;
     return 0;
 }
 

@@ -26,15 +26,16 @@ int hip_fail(hipError_t e, const char *what, const char *file, int line);
         return 1;                    \
     } while (0)
 
-/* how a sample range is cut into work items; a pure function of the range and n_split so that
- * summation order never depends on launch geometry */
+/* how a sample range is cut into work items; a pure function of the range, n_split and the image size so that
+ * summation order never depends on launch geometry (grid, GPU, tile share) */
 struct SlicePlan {
     int sample_begin;
     int n_samples;
     int n_split;
     int slices_per_split;
 };
-SlicePlan make_slice_plan(int sample_begin, int sample_end, int n_split);
+/* n_tiles: 8x8-pixel tile slots of the image (macro tiles x 64): small launches get shorter slices */
+SlicePlan make_slice_plan(int sample_begin, int sample_end, int n_split, int64_t n_tiles);
 /* samples [s0, s1) of slice `slice`: split buffer z = slice / slices_per_split takes the z-th of n_split equal parts
  * of the range, cut again into slices_per_split equal parts */
 void slice_range(const SlicePlan &pl, int slice, int &s0, int &s1);

@@ -56,7 +56,7 @@ HIT_DTYPE = np.dtype([("entity", "<i4"), ("triangle", "<i4"), ("t", "<f4"), ("bu
 ABI_SYMBOLS = [
     "pt_last_error", "pt_device_count", "pt_device_name", "pt_scene_create", "pt_scene_destroy", "pt_scene_add_material",
     "pt_scene_add_mesh", "pt_scene_add_sphere", "pt_scene_set_hdri", "pt_scene_commit", "pt_scene_clone", "pt_scene_save", "pt_scene_load", "pt_octree_builds", "pt_scene_octree_info",
-    "pt_scene_octree_dump", "pt_scene_device_bytes", "pt_trace_rays", "pt_camera_rays", "pt_sample_hdri", "pt_sample_material", "pt_box_intersects_triangle", "pt_child_tables", "pt_render_accumulate", "pt_render_accumulate_tiles",
+    "pt_scene_octree_dump", "pt_scene_device_bytes", "pt_trace_rays", "pt_camera_rays", "pt_sample_hdri", "pt_sample_material", "pt_box_intersects_triangle", "pt_child_tables", "pt_render_accumulate", "pt_render_accumulate_tiles", "pt_render_slices",
     "pt_render_accumulate_noalloc", "pt_noalloc_max_partial_bytes", "pt_scene_set_launch", "pt_scene_get_launch", "pt_scene_render_residency",
     "pt_scene_set_profiling", "pt_scene_schedule_counters", "pt_scene_last_render_kernel_ms", "pt_compound_buffers", "pt_reduce_sum", "pt_apply_filter", "pt_make_gaussian", "pt_make_mean", "pt_normalize_image", "pt_apply_threshold",
     "pt_image_add", "pt_apply_aces", "pt_gamma_correct", "pt_post_chain", "pt_malloc", "pt_free", "pt_memset", "pt_upload",
@@ -98,6 +98,7 @@ def lib():
         L.pt_box_intersects_triangle.argtypes = [vp, vp, vp, vp, vp, i32, C.POINTER(C.c_int)]
         L.pt_child_tables.argtypes = [vp, vp]
         L.pt_render_accumulate.argtypes = [vp, C.POINTER(Camera), u32, i32, i32, i32, vp, vp, vp]
+        L.pt_render_slices.argtypes = [C.POINTER(Camera), i32, i32, i32, C.POINTER(C.c_int)]
         L.pt_render_accumulate_tiles.argtypes = [vp, C.POINTER(Camera), u32, i32, i32, i32, vp, i32, i32, vp, vp]
         L.pt_render_accumulate_noalloc.argtypes = [vp, C.POINTER(Camera), u32, i32, i32, i32, vp, vp]
         L.pt_noalloc_max_partial_bytes.argtypes = []
@@ -412,6 +413,13 @@ def scene_from_description(desc, device=0, commit=True):
     c = desc["camera"]
     cam = make_camera(c["position"], c["direction"], c["res"], c["focal_length"], c["aperture"], c["focus_distance"])
     return sc, cam
+
+
+def render_slices(cam, sample_begin, sample_end, n_split=4):
+    """Sample slices (= partial images of the workspace) of a pt_render_accumulate call with these arguments."""
+    n = C.c_int(0)
+    check(lib().pt_render_slices(C.byref(cam), sample_begin, sample_end, n_split, C.byref(n)))
+    return int(n.value)
 
 
 def camera_rays(cam, seed, sample, device=0):

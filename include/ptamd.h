@@ -195,6 +195,11 @@ int pt_child_tables(uint8_t *set_out, uint8_t *mir_out);
 int pt_render_accumulate(pt_scene *scene, const pt_camera *camera, uint32_t seed,
                          int sample_begin, int sample_end, int n_split, float *d_split,
                          pt_counters *counters, void *stream);
+/* Slices of samples a pt_render_accumulate call with these arguments cuts its sample range into (its work items are
+ * 8x8-pixel tile x slice; its workspace and pt_render_accumulate_noalloc's scratch hold one W x H x 12-byte partial image
+ * per slice): n_split x min(64 / n_split, ceil(ceil(samples / n_split) / L)), L = 8 samples per slice, or 4 for a launch
+ * of fewer than 32768 work items.  No counterpart in the reference, whose slicing is fixed (8 x 4, src/renderer.cu:240-241). */
+int pt_render_slices(const pt_camera *camera, int sample_begin, int sample_end, int n_split, int *slices);
 /* pt_render_accumulate for one of tile_ranks interleaved shares of the image's 8x8-pixel tiles (share tile_rank takes every
  * tile_ranks-th tile of the tile sequence, so all shares see the same mix of scene content); pixels of other tiles are
  * left unchanged.  The reference's own grid has this tile axis (src/renderer.cu:219-223); it is the axis to shard over
@@ -210,8 +215,7 @@ int pt_render_accumulate_tiles(pt_scene *scene, const pt_camera *camera, uint32_
  * cursors and slice partials live in a fixed array of PT_NOALLOC_SCRATCH_BYTES in the library's device
  * image instead of a workspace grown with hipMalloc.  Loading the library costs that much memory on every
  * GPU it runs on, until the process ends, whether or not this entry point is called.  The plan of a call
- * has slices = n_split x min(64 / n_split, ceil(ceil(samples / n_split) / 8)) slices of samples, each with
- * a partial image of W x H x 12 bytes.  When they fit pt_noalloc_max_partial_bytes() together (640x360: 24
+ * has pt_render_slices() slices of samples, each with a partial image of W x H x 12 bytes.  When they fit pt_noalloc_max_partial_bytes() together (640x360: 24
  * slices) the call is one launch; otherwise it renders as many slices per launch as fit beside one image
  * that carries the running sum of the current split buffer (1920x1080: one slice per launch), adding them
  * up in pt_render_accumulate's order.  It fails, with a clear error and nothing written, only when two
