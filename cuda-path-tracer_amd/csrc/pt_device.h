@@ -116,7 +116,8 @@ struct Lane {
     uint32_t framed;         /* bit s: slot s holds a frame (a node with members left); see node_block */
     int32_t a;
     /* triangle run (octree leaf or brute-force mesh) */
-    uint32_t tri_cur, tri_left;   /* byte offset of the run's next triangle pair, triangles still to test */
+    uint32_t tri_cur, tri_left;   /* byte offset of the run's next triangle pair, triangles still to test (0: no run pending) */
+    uint32_t spec_mark;           /* counting builds: the lane's node_visits when its pending leaf was entered (see node_block, SPEC) */
     /* a run that accepted a test shows in best.entity (== ent - 1: an entity is visited once per ray and an octree walk
      * ends with the first leaf that accepts); a run that is an octree leaf shows in path != 0 */
 };
@@ -235,6 +236,7 @@ __device__ __forceinline__ void lane_start_ray(Lane &L, V3 o, V3 d) {
     L.o = o; L.d = d;
     L.best.t = FLT_MAX; L.best.bu = 0.f; L.best.bv = 0.f; L.best.entity = -1; L.best.rec = 0;
     L.ent = 0;
+    L.tri_left = 0u;
     L.mode = M_ENTITY;
 }
 
@@ -273,6 +275,7 @@ __device__ __forceinline__ void entity_visit(const PtSceneDev &sc, Lane &L, Stat
         L.tri_cur = e.tri_first << 4; L.tri_left = e.n_tris;
         L.path = 0;
         L.mode = M_LEAF;
+        if (STATS) L.spec_mark = st.node_visits;
         return;
     }
     V3 o = L.o, d = L.d;
@@ -376,13 +379,26 @@ __device__ __forceinline__ void entity_prepass(const PtSceneDev &sc, Lane &L, St
  * Copies only; tM is recomputed by the same expression, so every value is the one the recursion would hold.
  * (A counting build keeps a frame while rejected members are left to count, and may find a frame without members
  * on return: it then returns again in its next trip.)
+ *
+ * Walking ahead of a leaf (SPEC: the builds with the cooperative leaf phase).  A lane that enters a leaf does not stop
+ * for it: the leaf's run becomes the lane's PENDING run (tri_left != 0) and the lane keeps walking as if the leaf accepted
+ * nothing, which is what happens six times out of seven -- the walk itself never looks at the closest hit, only triangle
+ * tests do.  The run is tested in the wave's next cooperative phase.  If it accepted a test, the reference's walk ended at
+ * that leaf (dgf:188) and the steps taken since are dropped (the phase sends the lane on to its next entity; a counting
+ * build takes its node count back to the mark set on entry); otherwise the lane simply is where the reference would be by
+ * now.  One run at a time: a lane that reaches its next leaf, or the end of its walk, with a run still pending waits there
+ * (M_LEAF) -- the leaf's member stays in the list and is taken again after the phase -- so triangle tests keep their order.
  */
-template <bool STATS, bool PREPASS>
+template <bool STATS, bool PREPASS, bool SPEC>
 __device__ __forceinline__ void node_block(const PtSceneDev &sc, Lane &L, Stats &st, float4 *stack, uint32_t *stack1, int stride) {
     if ((L.todo & 0xFFu) == 0u) {
         if (STATS) st.node_visits += __popc((L.todo >> 8) & 0xFFu);
         const uint32_t above = L.framed >> L.rem;              /* bit 0: the parent's slot */
-        if (above == 0u) { L.mode = next_entity_mode<PREPASS>(sc, L); return; }     /* walk finished without an accepted leaf */
+        if (above == 0u) {                                     /* walk finished without an accepted leaf */
+            if (SPEC && L.tri_left != 0u) { L.path = 0u; L.mode = M_LEAF; }       /* ... but for the pending one: like a run outside an octree */
+            else L.mode = next_entity_mode<PREPASS>(sc, L);
+            return;
+        }
         const int up = __builtin_ctz(above);
         const int slot = L.rem + up;
         const float4 s = stack[slot * stride];
@@ -421,6 +437,8 @@ __device__ __forceinline__ void node_block(const PtSceneDev &sc, Lane &L, Stats 
         L.todo = w;
         if (STATS && (w & 0xFFu) == 0u) return;               /* only rejected members were left: counted in the next trip */
     }
+    const uint32_t todo_before = L.todo;
+    const uint32_t visits_before = STATS ? st.node_visits : 0u;
     const int curr = __builtin_ctz(L.todo);                   /* lowest go bit = next member (go != 0 here) */
     if (STATS) {
         const uint32_t below = (1u << curr) - 1u;
@@ -436,8 +454,15 @@ __device__ __forceinline__ void node_block(const PtSceneDev &sc, Lane &L, Stats 
     const PtNode rec = sc.nodes[child];
     if (L.rem == 0) {                     /* leaf: dgf:146-157 */
         if (rec.b != 0u) {
-            L.tri_cur = rec.a << 4; L.tri_left = rec.b;
-            L.mode = M_LEAF;
+            if (SPEC && L.tri_left != 0u) {               /* a run is pending already: wait here, the member goes back into the list */
+                L.todo = todo_before;
+                if (STATS) st.node_visits = visits_before;
+                L.mode = M_LEAF;
+            } else {
+                L.tri_cur = rec.a << 4; L.tri_left = rec.b;
+                if (STATS) L.spec_mark = st.node_visits;
+                if (!SPEC) L.mode = M_LEAF;               /* (SPEC: the lane walks on, see above) */
+            }
         }
         return;
     }
@@ -619,8 +644,9 @@ __device__ __forceinline__ void wave_lds_fence() {
 
 template <bool STATS>
 __device__ __forceinline__ void leaf_coop(const PtSceneDev &sc, Lane &L, Stats &st, CoopLds *C, int lane) {
-    const bool mine = L.mode == M_LEAF;
-    const uint32_t my_left = mine ? L.tri_left : 0u;
+    /* every lane with a pending run takes part as an owner, whether it waits at the leaf or has walked on (a lane without a
+     * run has tri_left == 0) */
+    const uint32_t my_left = L.tri_left;
     const uint32_t my_pairs = (my_left + 1u) >> 1;
     const uint32_t np = min(my_pairs, kCoopMaxPairs);
     /* exclusive prefix and total of np over the wave: a scan on the cross-lane data path, log steps inside each row of
@@ -747,7 +773,12 @@ __device__ __forceinline__ void leaf_coop(const PtSceneDev &sc, Lane &L, Stats &
         L.tri_cur += np * (uint32_t)sizeof(PtTriPair);
         L.tri_left -= min(my_left, 2u * np);
         const bool finished = np != 0u && L.tri_left == 0u;
-        const int after = (L.path != 0u && L.best.entity != L.ent - 1) ? M_NODE : next_entity_mode<false>(sc, L);
+        /* a finished run that accepted a test ends the walk of its entity, wherever the lane has walked to meanwhile; one that
+         * did not leaves a lane that walked on where it is, and sends a lane that waited back to its node (or, after a run
+         * outside an octree or at the end of a walk, on to the next entity) */
+        const bool accepted = L.best.entity == L.ent - 1;
+        const int after = (L.path != 0u && !accepted) ? M_NODE : next_entity_mode<false>(sc, L);
+        if (STATS && finished && accepted) st.node_visits = L.spec_mark;
         L.mode = finished ? after : L.mode;
     }
 }
@@ -777,20 +808,39 @@ __device__ __forceinline__ void trace_wave(const PtSceneDev &sc, Lane &L, Stats 
                                            int stride, int done_quota, int leaf_quota, CoopLds *coop, int lane) {
     static_assert(!(LOG && COOP), "the cooperative leaf phase keeps no test log");
     static_assert(!(PREPASS && COOP), "the entity pre-pass belongs to the builds for small scenes");
+    bool phase_due = false;
     for (;;) {
-        const int n_ent = count_lanes(L.mode == M_ENTITY);
+        /* The lane counts that pick the next block cost a vector compare and a few scalar instructions each, and a wave in the
+         * middle of its walk alternates between a cooperative phase and a couple of node trips: those two are decided on three
+         * counts, in one pass of this loop (a phase when enough runs wait, then node trips while the walkers are a majority
+         * and the finished lanes no quorum yet).  Everything else takes the full set of counts below. */
+        int n_pend = 0;
+        if (COOP) {
+            n_pend = count_lanes(L.tri_left != 0u);
+            if (n_pend >= leaf_quota || phase_due) { leaf_coop<STATS>(sc, L, st, coop, lane); n_pend = 0; phase_due = false; }
+        }
         const int n_node = count_lanes(L.mode == M_NODE);
-        const int n_leaf = count_lanes(L.mode == M_LEAF);
-        if (n_ent + n_node + n_leaf == 0) return;
-        /* leave to shade / refill once the finished lanes are a quorum and no block has more lanes waiting */
         const int n_done = count_lanes(L.mode == M_DONE);
-        if (n_done >= done_quota && n_done >= n_node && n_done >= n_leaf) return;
-        /* a cooperative leaf phase serves every waiting run with all 64 lanes: it runs as soon as `leaf_quota`
-         * runs wait (about enough pairs for a full trip), and the walk stops for it */
-        const bool leaf_first = COOP ? (n_leaf >= leaf_quota || n_leaf > n_node) : (n_leaf > n_node);
+        int which = -1;
+        int n_leaf = 0;
+        if (COOP && n_node >= 32 && n_done < done_quota) {
+            which = 1;
+        } else {
+            const int n_ent = count_lanes(L.mode == M_ENTITY);
+            n_leaf = count_lanes(L.mode == M_LEAF);
+            /* runs waiting for a cooperative phase: those of the lanes that wait at a leaf and those of lanes that have walked on */
+            if (!COOP) n_pend = n_leaf;
+            else if (n_pend == 0) n_pend = count_lanes(L.tri_left != 0u);
+            if (n_ent + n_node + n_leaf == 0) return;
+            /* leave to shade / refill once the finished lanes are a quorum and no block has more lanes waiting */
+            if (n_done >= done_quota && n_done >= n_node && n_done >= n_leaf) return;
+            /* a cooperative leaf phase serves every waiting run with all 64 lanes: it runs as soon as `leaf_quota`
+             * runs wait (about enough pairs for a full trip), and the walk stops for it */
+            const bool leaf_first = COOP ? (n_pend >= leaf_quota || n_leaf > n_node) : (n_leaf > n_node);
+            which = (n_ent >= n_node && n_ent >= n_leaf) ? 0 : (!leaf_first ? 1 : 2);
+        }
         /* one of three blocks runs; written as three independent conditionals (not an if / else-if chain): every block
          * then is a plain divergent region that updates the lane state in place */
-        const int which = (n_ent >= n_node && n_ent >= n_leaf) ? 0 : (!leaf_first ? 1 : 2);
         if (which == 0) {
             if (STATS) st.ent_trips++;
             if (L.mode == M_ENTITY) { if (STATS) st.ent_lanes++; entity_block<STATS, PREPASS, COOP>(sc, L, st); }
@@ -802,14 +852,14 @@ __device__ __forceinline__ void trace_wave(const PtSceneDev &sc, Lane &L, Stats 
 #pragma unroll
                 for (int u = 0; u < PT_NODE_GROUP; u++) {
                     if (STATS) st.node_trips++;
-                    if (L.mode == M_NODE) { if (STATS) st.node_lanes++; node_block<STATS, PREPASS>(sc, L, st, stack, stack1, stride); }
+                    if (L.mode == M_NODE) { if (STATS) st.node_lanes++; node_block<STATS, PREPASS, COOP>(sc, L, st, stack, stack1, stride); }
                 }
             } while ((trips += PT_NODE_GROUP) < PT_TRIPS && PT_KEEP_NODE * __popcll(__ballot(L.mode == M_NODE)) >= n_node &&
-                     !(COOP && __popcll(__ballot(L.mode == M_LEAF)) >= leaf_quota));
+                     !(COOP && __popcll(__ballot(L.tri_left != 0u)) >= leaf_quota));
         }
         if (which == 2) {
             if (COOP) {
-                leaf_coop<STATS>(sc, L, st, coop, lane);
+                phase_due = true;          /* (the one copy of the phase's code is at the head of the loop) */
             } else {
                 int trips = 0;
 #pragma nounroll

@@ -360,6 +360,7 @@ __global__ void __launch_bounds__(kBlock) trace_kernel(PtSceneDev sc, const floa
     const int64_t step = (int64_t)gridDim.x * kBlock;
     int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x - step;
     L.mode = M_DONE;            /* "finished ray -1": the first trip only fetches */
+    L.tri_left = 0u;
     bool first = true;
     for (;;) {
         if (L.mode == M_DONE) {
@@ -557,6 +558,7 @@ __global__ void __launch_bounds__(kBlock, WAVES) render_kernel(RenderParams P) {
     V3 accum = mk(0.f, 0.f, 0.f), result = mk(0.f, 0.f, 0.f), atten = mk(1.f, 1.f, 1.f);
     Lane L;
     L.mode = M_IDLE;
+    L.tri_left = 0u;
     Stats st;
     stats_zero(st);
     TriLog lg;
