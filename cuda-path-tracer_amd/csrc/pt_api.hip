@@ -74,7 +74,7 @@ struct pt_scene {
     /* launch choices of the render kernel (defaults picked at commit, pt_scene_set_launch overrides) */
     bool heavy = false;        /* traversal-dominated scene: render with the many-waves build of the kernel */
     int quorum = 12;           /* finished lanes per wave that make it leave the geometry blocks to shade / refill */
-    int leaf_quota = 20;       /* triangle runs waiting per wave at which it tests them before walking on */
+    int leaf_quota = 12;       /* triangle runs waiting per wave at which it tests them before walking on */
     bool build_fixed = false, quorum_fixed = false, leaf_quota_fixed = false;   /* set by the caller or the environment: commit keeps them */
     PtSceneDev dev{};
     std::vector<void *> allocs;
@@ -767,7 +767,7 @@ int pt_scene_commit(pt_scene *scene) {
         else if (scene->heavy) scene->quorum = (textured || few_waves) ? 48 : 40;
         else scene->quorum = textured ? 40 : 12;
     }
-    if (!scene->leaf_quota_fixed) scene->leaf_quota = (scene->heavy && render_workgroups_per_cu(max_depth, true) < 4) ? 12 : 20;
+    if (!scene->leaf_quota_fixed) scene->leaf_quota = 12;      /* (phases run whole trips of 64 pairs and serve waiting lanes first: 12 runs is the optimum of the four- and the three-wave instantiation alike) */
     if (const char *k = getenv("PTAMD_QUORUM")) {
         const int q = atoi(k);
         if (q >= 1 && q <= 64) { scene->quorum = q; scene->quorum_fixed = true; }

@@ -648,20 +648,32 @@ __device__ __forceinline__ void leaf_coop(const PtSceneDev &sc, Lane &L, Stats &
      * run has tri_left == 0) */
     const uint32_t my_left = L.tri_left;
     const uint32_t my_pairs = (my_left + 1u) >> 1;
-    const uint32_t np = min(my_pairs, kCoopMaxPairs);
-    /* exclusive prefix and total of np over the wave: a scan on the cross-lane data path, log steps inside each row of
-     * 16 lanes (a lane without a source adds zero), then the last lane of a row broadcast into the rows after it.
-     * All 64 lanes are active here. */
-    uint32_t incl = np;
+    const uint32_t np_all = min(my_pairs, kCoopMaxPairs);
+    /* The pending pairs are laid end to end in two groups: first the runs of the lanes that WAIT for the phase (M_LEAF), in
+     * lane order, then the runs of the lanes that have walked on.  Exclusive prefixes and totals of both groups come from one
+     * scan of a word with a 16-bit count per group (at most 64 * kCoopMaxPairs pairs each): a scan on the cross-lane data
+     * path, log steps inside each row of 16 lanes (a lane without a source adds zero), then the last lane of a row broadcast
+     * into the rows after it.  All 64 lanes are active here. */
+    const bool waits = L.mode == M_LEAF;
+    const uint32_t both = waits ? np_all : np_all << 16;
+    uint32_t incl = both;
     incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x111, 0xf, 0xf, true);      /* row_shr:1 */
     incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x112, 0xf, 0xf, true);      /* row_shr:2 */
     incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x114, 0xf, 0xf, true);      /* row_shr:4 */
     incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x118, 0xf, 0xf, true);      /* row_shr:8 */
     incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x142, 0xa, 0xf, false);     /* row_bcast:15 into rows 1, 3 */
     incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x143, 0xc, 0xf, false);     /* row_bcast:31 into rows 2, 3 */
-    const uint32_t excl = incl - np;
-    const uint32_t T = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-    const unsigned long long runs = __ballot(np != 0u);
+    const uint32_t before = incl - both;
+    const uint32_t totals = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+    const uint32_t T_wait = totals & 0xFFFFu, T_all = T_wait + (totals >> 16);
+    const uint32_t excl = waits ? (before & 0xFFFFu) : T_wait + (before >> 16);      /* position of the lane's first pair */
+    /* Whole trips only: of more than 64 pending pairs the phase takes a multiple of 64 and leaves the tail pending for the
+     * next phase, where new runs fill the trip up -- the tail being runs of lanes that walk on meanwhile, as long as there
+     * are such.  (A run that is cut continues where it stopped, like one longer than kCoopMaxPairs pairs.) */
+    const uint32_t T = T_all >= 64u ? (T_all & ~63u) : T_all;
+    const uint32_t np = min(np_all, T - min(excl, T));
+    const unsigned long long runs_wait = __ballot(np != 0u && waits), runs_walk = __ballot(np != 0u && !waits);
+    const uint32_t rank = waits ? lanes_below(runs_wait) : (uint32_t)__popcll(runs_wait) + lanes_below(runs_walk);      /* runs before this one */
     /* the two constants are made here: left to the compiler they are hoisted out of the kernel's work loop, where one
      * sat in a register pair for good and the other was spilled and came back from scratch memory in every phase */
     unsigned long long zeros, ones;
@@ -671,7 +683,7 @@ __device__ __forceinline__ void leaf_coop(const PtSceneDev &sc, Lane &L, Stats &
     wave_lds_fence();
     if (np != 0u) {
         atomicOr(&C->starts[excl >> 6], 1ull << (excl & 63u));
-        C->own[lanes_below(runs)] = (uint32_t)lane | (excl << 8);
+        C->own[rank] = (uint32_t)lane | (excl << 8);
     }
     wave_lds_fence();
     const uint32_t my_cur = L.tri_cur;
@@ -749,7 +761,8 @@ __device__ __forceinline__ void leaf_coop(const PtSceneDev &sc, Lane &L, Stats &
                 const unsigned long long key = ((unsigned long long)__float_as_uint(bt) << 32) | (unsigned long long)(2u * j + slot);
                 atomicMin(&C->res[owner], key);
                 wave_lds_fence();
-                if (*(volatile unsigned long long *)&C->res[owner] == key) {
+                /* (read back through an LDS pointer: as a volatile generic access it became a flat load with a full wait) */
+                if (__hip_atomic_load((__attribute__((address_space(3))) unsigned long long *)&C->res[owner], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT) == key) {
                     C->win[owner][0] = bu;
                     C->win[owner][1] = bv;
                 }

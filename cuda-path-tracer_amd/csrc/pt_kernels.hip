@@ -98,7 +98,7 @@ __device__ __forceinline__ V3 tex_rgb(const uint8_t *data, int w, int h, float u
 #ifdef PT_PROBE_TEXEL0
     x = 0; y = 0;
 #endif
-    const uint8_t *p = data + 3 * ((size_t)y * (size_t)w + (size_t)x);
+    const __attribute__((address_space(1))) uint8_t *p = (const __attribute__((address_space(1))) uint8_t *)data + 3 * ((size_t)y * (size_t)w + (size_t)x);
     const float k = 1.0f / 255.0f;
     return mk((float)p[0] * k, (float)p[1] * k, (float)p[2] * k);
 }
@@ -108,7 +108,7 @@ __device__ __forceinline__ float tex_gray(const uint8_t *data, int w, int h, flo
 #ifdef PT_PROBE_TEXEL0
     x = 0; y = 0;
 #endif
-    return (float)data[(size_t)y * (size_t)w + (size_t)x] * (1.0f / 255.0f);
+    return (float)((const __attribute__((address_space(1))) uint8_t *)data)[(size_t)y * (size_t)w + (size_t)x] * (1.0f / 255.0f);
 }
 
 /* The four material samples of one hit (src/material.cuh:21-44: sample_normal, sample_albedo, sample_smoothness,
@@ -130,8 +130,12 @@ __device__ __forceinline__ void sample_material(const PtMaterial &m, float u, fl
         x = 0; y = 0;
 #endif
         const uint32_t rec = (((y >> 2) * m.packed_tiles_x + (x >> 2)) << 4) | ((y & 3u) << 2) | (x & 3u);
-        const char *p = reinterpret_cast<const char *>(m.packed) + (rec << m.packed_shift);      /* 32-bit byte offset (checked when packed) */
-        const uint2 w = *reinterpret_cast<const uint2 *>(p);
+        /* 32-bit byte offset (checked when packed).  The pointer comes out of the material record, so the compiler cannot tell
+         * that it points to global memory: said explicitly, or the texel loads become flat loads */
+        typedef const __attribute__((address_space(1))) char *gptr;
+        gptr p = (gptr)(reinterpret_cast<const char *>(m.packed)) + (rec << m.packed_shift);
+        typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+        const u32x2 w = *(const __attribute__((address_space(1))) u32x2 *)p;
         if (STATS) st.tex_fetches += (uint32_t)__popc(m.packed_mask);
         if (m.packed_mask & (1u << PT_MAP_NORMAL)) {
             const V3 c = mk((float)(w.x >> 24) * k, (float)(w.y & 0xFFu) * k, (float)((w.y >> 8) & 0xFFu) * k);
@@ -140,7 +144,7 @@ __device__ __forceinline__ void sample_material(const PtMaterial &m, float u, fl
         if (m.packed_mask & (1u << PT_MAP_ALBEDO)) o.albedo = mk((float)(w.x & 0xFFu) * k, (float)((w.x >> 8) & 0xFFu) * k, (float)((w.x >> 16) & 0xFFu) * k);
         if (m.packed_mask & (1u << PT_MAP_SMOOTHNESS)) o.smoothness = (float)((w.y >> 16) & 0xFFu) * k;
         if (m.packed_mask & (1u << PT_MAP_SPECULAR)) {
-            const uint32_t w2 = *reinterpret_cast<const uint32_t *>(p + 8);
+            const uint32_t w2 = *(const __attribute__((address_space(1))) uint32_t *)(p + 8);
             o.specular = mk((float)(w2 & 0xFFu) * k, (float)((w2 >> 8) & 0xFFu) * k, (float)((w2 >> 16) & 0xFFu) * k);
         }
         return;

@@ -120,8 +120,7 @@ int pt_scene_set_hdri(pt_scene *scene, const float *rgb, int w, int h, float exp
  * heavy for scenes with a large octree, light otherwise -- and the quorum (62 without any octree; heavy
  * build: 48 with textured materials or an octree of depth 8 and more, else 40; light build: 40 / 12); the
  * environment variables PTAMD_KERNEL = heavy | light, PTAMD_QUORUM = 1..64 and PTAMD_LEAF_QUOTA = 1..65 (heavy
- * build: triangle runs waiting in a wave at which it tests them, default 20, 12 for an octree of depth 8 and
- * more) fix them.  Limits: 2^29 octree nodes and
+ * build: triangle runs waiting in a wave at which it tests them, default 12) fix them.  Limits: 2^29 octree nodes and
  * 4 GiB of triangle pairs per scene. */
 int pt_scene_commit(pt_scene *scene);
 /* ---- one scene, several GPUs (no counterpart in the reference, which builds and uploads one scene in one process for
