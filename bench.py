@@ -218,6 +218,7 @@ def main():
     counters = step(want_counters=True)
     torch.cuda.synchronize()
     schedule = scene.schedule_counters()
+    schedule["wave_time_share"] = scene.block_cycles()
     scene.set_profiling(True)
     fence()
     kernel_ms = []

@@ -93,6 +93,7 @@ struct pt_scene {
 
 namespace {
 
+constexpr int kStatSlots = 24;       /* counter block of a counted launch: 7 work counters, 8 scheduling counters, 5 wave life times */
 constexpr int kMaxQueues = 4096;     /* upper bound on the persistent grid (workgroups) */
 
 /*
@@ -779,8 +780,8 @@ int pt_scene_commit(pt_scene *scene) {
     }
 
     PT_HIP(hipMalloc((void **)&scene->d_tickets, (kMaxQueues + 1) * sizeof(uint32_t)));
-    PT_HIP(hipMalloc((void **)&scene->d_stats, 16 * sizeof(unsigned long long)));
-    PT_HIP(hipMemset(scene->d_stats, 0, 16 * sizeof(unsigned long long)));
+    PT_HIP(hipMalloc((void **)&scene->d_stats, kStatSlots * sizeof(unsigned long long)));
+    PT_HIP(hipMemset(scene->d_stats, 0, kStatSlots * sizeof(unsigned long long)));
     if (scratch_address(scene->device, &scene->scratch)) return 1;
     scene->committed = true;
     return 0;
@@ -863,7 +864,7 @@ int pt_trace_rays(pt_scene *scene, const float *rays, int64_t n, pt_hit *hits, i
             /* entries past a ray's test count read as 0 */
             if (hipMemsetAsync(tmp_log, 0, (size_t)n * log_stride * 4, stream) != hipSuccess) { rc = 1; set_error("pt_trace_rays: memset failed"); break; }
         }
-        if (counters && hipMemsetAsync(scene->d_stats, 0, 16 * sizeof(unsigned long long), stream) != hipSuccess) { rc = 1; set_error("pt_trace_rays: memset failed"); break; }
+        if (counters && hipMemsetAsync(scene->d_stats, 0, kStatSlots * sizeof(unsigned long long), stream) != hipSuccess) { rc = 1; set_error("pt_trace_rays: memset failed"); break; }
         rc = launch_trace(scene->dev, d_rays, n, d_hits, d_log, log_stride, counters ? scene->d_stats : nullptr, stream);
         if (rc) break;
         if (!hits_dev && hipMemcpyAsync(hits, d_hits, (size_t)n * sizeof(pt_hit), hipMemcpyDeviceToHost, stream) != hipSuccess) { rc = 1; set_error("pt_trace_rays: hit download failed"); break; }
@@ -1012,7 +1013,7 @@ int pt_render_accumulate_tiles(pt_scene *scene, const pt_camera *camera, uint32_
     PT_HIP(hipMemsetAsync(scene->d_tickets, 0, (kMaxQueues + 1) * sizeof(uint32_t), stream));
     /* a share of the tiles leaves the other tiles' partials unwritten: they must read as zero in the compounding kernel */
     if (tile_ranks > 1) PT_HIP(hipMemsetAsync(p.partials, 0, need, stream));
-    if (counters) PT_HIP(hipMemsetAsync(scene->d_stats, 0, 16 * sizeof(unsigned long long), stream));
+    if (counters) PT_HIP(hipMemsetAsync(scene->d_stats, 0, kStatSlots * sizeof(unsigned long long), stream));
     if (scene->profiling) {
         if (ensure_events(scene)) return 1;
         PT_HIP(hipEventRecord(scene->ev_start, stream));
@@ -1194,6 +1195,18 @@ int pt_scene_schedule_counters(pt_scene *scene, uint64_t out[8]) {
     unsigned long long h[16];
     PT_HIP(hipMemcpy(h, scene->d_stats, sizeof h, hipMemcpyDeviceToHost));
     for (int i = 0; i < 8; i++) out[i] = h[7 + i];
+    return 0;
+}
+
+int pt_scene_block_cycles(pt_scene *scene, uint64_t out[5]) {
+    if (!scene || !out) PT_FAIL("pt_scene_block_cycles: null argument");
+    if (!scene->committed) PT_FAIL("pt_scene_block_cycles: scene not committed");
+    if (!scene->stats_valid) PT_FAIL("pt_scene_block_cycles: no render launch with counters since the scene was committed");
+    DeviceGuard g(scene->device);
+    if (!g.ok) PT_FAIL("pt_scene_block_cycles: cannot select device");
+    unsigned long long h[kStatSlots];
+    PT_HIP(hipMemcpy(h, scene->d_stats, sizeof h, hipMemcpyDeviceToHost));
+    for (int i = 0; i < 5; i++) out[i] = h[15 + i];
     return 0;
 }
 

@@ -66,10 +66,15 @@ struct Stats {
     /* scheduling diagnostics (per lane: trips of each block this lane took part in; lane 0 also
      * counts the trips its wave ran, so lanes / (64 * trips) is the block's lane occupancy) */
     uint32_t ent_lanes, node_lanes, leaf_lanes, front_lanes, ent_trips, node_trips, leaf_trips, front_trips;
+    /* shader-clock cycles the wave spent inside each geometry block and inside trace_wave as a whole (wave-uniform; the
+     * clock runs on while other waves of the SIMD issue, so these are shares of a wave's life time, not issue cycles) */
+    uint64_t cyc_ent, cyc_node, cyc_leaf, cyc_trace;
 };
+__device__ __forceinline__ uint64_t wave_clock() { return __builtin_readcyclecounter(); }
 __device__ __forceinline__ void stats_zero(Stats &s) {
     s.segments = s.aabb_tests = s.node_visits = s.tri_tests = s.env_lookups = s.tex_fetches = s.paths = 0;
     s.ent_lanes = s.node_lanes = s.leaf_lanes = s.front_lanes = s.ent_trips = s.node_trips = s.leaf_trips = s.front_trips = 0;
+    s.cyc_ent = s.cyc_node = s.cyc_leaf = s.cyc_trace = 0;
 }
 
 struct Best {
@@ -222,7 +227,10 @@ __device__ __forceinline__ bool slab_test(const float mn[3], const float mx[3], 
  * of the same box passes later (which still runs): skipping the others changes no result, only saves them a trip each.
  * Scenes with fewer than 6 entities (the pass costs more than the trips it saves: three-entity teapot scene 6110 against
  * 6925 Mpaths/s with it, twelve-entity box scene 8370 against 6915) or more than 31 (the mask is one word) go without. */
-static constexpr int kPrepassMinEntities = 6;
+#ifndef PT_PREPASS_MIN
+#define PT_PREPASS_MIN 6
+#endif
+static constexpr int kPrepassMinEntities = PT_PREPASS_MIN;
 __device__ __forceinline__ bool uses_entity_mask(const PtSceneDev &sc) { return sc.n_entities >= kPrepassMinEntities && sc.n_entities <= 31; }
 
 /* after an entity has been dealt with: on to the next one, or the ray is finished */
@@ -249,14 +257,14 @@ __device__ __forceinline__ void lane_start_ray(Lane &L, V3 o, V3 d) {
  */
 /* (the block proper, on a view E of the entity's record: the record itself, or a copy of its rows in registers) */
 template <bool STATS, bool PREPASS, typename E>
-__device__ __forceinline__ void entity_visit(const PtSceneDev &sc, Lane &L, Stats &st, const E &e, const PtEntity *ep, bool masked) {
+__device__ __forceinline__ void entity_visit(const PtSceneDev &sc, Lane &L, Stats &st, const E &e, bool masked) {
     const int32_t ei = L.ent;
     L.ent = ei + 1;                       /* default: move on to the next entity, or finish */
     L.mode = next_entity_mode<PREPASS>(sc, L);
     if (e.shape == PT_SHAPE_SPHERE) {     /* dgf:257-275; a sphere hit clears the triangle */
-        const V3 dd = L.o - mk(ep->center[0], ep->center[1], ep->center[2]);
+        const V3 dd = L.o - mk(e.center[0], e.center[1], e.center[2]);
         const float p1 = -dot3(L.d, dd);
-        const float p2sqr = ((p1 * p1) - dot3(dd, dd)) + (ep->radius * ep->radius);
+        const float p2sqr = ((p1 * p1) - dot3(dd, dd)) + (e.radius * e.radius);
         if (!(p2sqr < 0)) {
             const float p2 = 1.0f / rsqrt_ieee(p2sqr);
             const float t = p1 - p2 > 0 ? p1 - p2 : p1 + p2;
@@ -304,38 +312,63 @@ __device__ __forceinline__ void entity_visit(const PtSceneDev &sc, Lane &L, Stat
     L.mode = M_NODE;
 }
 
+/* Entity records in LDS (an experiment, off: PT_LDS_ENTITIES = 0).  A scene of at most PT_LDS_ENTITIES entities has its records
+ * copied behind the node step's tables by every workgroup (pt_kernels.hip: load_lds_constants); the block then reads a record
+ * with seven 16-byte LDS loads issued together instead of global loads through the vector cache.  Measured with 32: the
+ * block's share of the waves' life time falls from a quarter to a seventh on the teapot and Cornell box scenes, and their
+ * throughput stays where it was (+0.2 %, +0.5 %): the other waves of the SIMD were covering those latencies already -- the kernel
+ * is bound by instruction issue.  The 3.5 KB of LDS cost the dragon scene (depth-8 stacks) its fourth workgroup per CU: -16 %. */
+#ifndef PT_LDS_ENTITIES
+#define PT_LDS_ENTITIES 0
+#endif
+static constexpr int kLdsEntities = PT_LDS_ENTITIES;
+static constexpr uint32_t kEntLdsByte = 3072u;      /* = sizeof(ChildTables), asserted where the LDS is laid out */
+struct EntityRows {
+    int32_t shape, material, octree_depth; uint32_t root_node; float aabb_min[3]; uint32_t tri_first; float aabb_max[3]; uint32_t n_tris;
+    float region_min[3]; uint32_t shade_base; float region_max[3]; int32_t has_uvs; float center[3]; float radius; uint32_t root_a, root_b;
+};
+
 template <bool STATS, bool PREPASS, bool TOGETHER>
-__device__ __forceinline__ void entity_block(const PtSceneDev &sc, Lane &L, Stats &st) {
+__device__ __forceinline__ void entity_block(const PtSceneDev &sc, Lane &L, Stats &st, bool lds_ents) {
     const bool masked = PREPASS && uses_entity_mask(sc);
     if (masked) {
         const uint32_t left = L.emask >> L.ent;
         if (left == 0u) { L.mode = M_DONE; return; }
         L.ent += __builtin_ctz(left);     /* entities in between are not worth a visit */
     } else if (L.ent >= sc.n_entities) { L.mode = M_DONE; return; }
-    /* TOGETHER: the rows of the record that a mesh needs are fetched at once, before anything is decided on them.  Read
-     * field by field where it is used, every decision (shape, box, octree depth, root region) waits for a fetch of its
-     * own, four in a row.  Pays for scenes of one large mesh (+2 % with 871 k triangles); scenes of many small meshes lose by
-     * it (box scene -6 %: most trips end at the box test).  (A sphere's centre and radius are fetched in its branch.) */
+    typedef int iv4 __attribute__((ext_vector_type(4)));
+    typedef float fv4 __attribute__((ext_vector_type(4)));
     const PtEntity *ep = &sc.entities[L.ent];
-    if (!TOGETHER) { entity_visit<STATS, PREPASS>(sc, L, st, *ep, ep, masked); return; }
-    struct { int32_t shape, material, octree_depth; uint32_t root_node; float aabb_min[3]; uint32_t tri_first; float aabb_max[3]; uint32_t n_tris;
-             float region_min[3]; uint32_t shade_base; float region_max[3]; int32_t has_uvs; uint32_t root_a, root_b; } e;
-    {
-        typedef int iv4 __attribute__((ext_vector_type(4)));
-        typedef float fv4 __attribute__((ext_vector_type(4)));
-        iv4 r0 = reinterpret_cast<const iv4 *>(ep)[0];
-        fv4 r1 = reinterpret_cast<const fv4 *>(ep)[1], r2 = reinterpret_cast<const fv4 *>(ep)[2];
-        fv4 r3 = reinterpret_cast<const fv4 *>(ep)[3], r4 = reinterpret_cast<const fv4 *>(ep)[4];
-        iv4 r6 = reinterpret_cast<const iv4 *>(ep)[6];
-        asm volatile("" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3), "+v"(r4), "+v"(r6));   /* all six here, whole: not split up and moved to their uses */
-        e.shape = r0.x; e.material = r0.y; e.octree_depth = r0.z; e.root_node = (uint32_t)r0.w;
-        e.aabb_min[0] = r1.x; e.aabb_min[1] = r1.y; e.aabb_min[2] = r1.z; e.tri_first = __float_as_uint(r1.w);
-        e.aabb_max[0] = r2.x; e.aabb_max[1] = r2.y; e.aabb_max[2] = r2.z; e.n_tris = __float_as_uint(r2.w);
-        e.region_min[0] = r3.x; e.region_min[1] = r3.y; e.region_min[2] = r3.z; e.shade_base = __float_as_uint(r3.w);
-        e.region_max[0] = r4.x; e.region_max[1] = r4.y; e.region_max[2] = r4.z; e.has_uvs = __float_as_int(r4.w);
-        e.root_a = (uint32_t)r6.y; e.root_b = (uint32_t)r6.z;
+    iv4 r0, r6;
+    fv4 r1, r2, r3, r4, r5;
+    if (lds_ents) {                       /* (uniform) */
+        const uint32_t at = kEntLdsByte + (uint32_t)L.ent * (uint32_t)sizeof(PtEntity);
+        const __attribute__((address_space(3))) fv4 *rows = (const __attribute__((address_space(3))) fv4 *)(uintptr_t)at;
+        const fv4 q0 = rows[0], q6 = rows[6];
+        r1 = rows[1]; r2 = rows[2]; r3 = rows[3]; r4 = rows[4]; r5 = rows[5];
+        r0 = __builtin_bit_cast(iv4, q0); r6 = __builtin_bit_cast(iv4, q6);
+    } else {
+        /* TOGETHER: the rows of the record that a mesh needs are fetched at once, before anything is decided on them.  Read
+         * field by field where it is used, every decision (shape, box, octree depth, root region) waits for a fetch of its
+         * own, four in a row.  Pays for scenes of one large mesh (+2 % with 871 k triangles); scenes of many small meshes lose by
+         * it (box scene -6 %: most trips end at the box test). */
+        if (!TOGETHER) { entity_visit<STATS, PREPASS>(sc, L, st, *ep, masked); return; }
+        r0 = reinterpret_cast<const iv4 *>(ep)[0];
+        r1 = reinterpret_cast<const fv4 *>(ep)[1]; r2 = reinterpret_cast<const fv4 *>(ep)[2];
+        r3 = reinterpret_cast<const fv4 *>(ep)[3]; r4 = reinterpret_cast<const fv4 *>(ep)[4];
+        r5 = reinterpret_cast<const fv4 *>(ep)[5];
+        r6 = reinterpret_cast<const iv4 *>(ep)[6];
+        asm volatile("" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3), "+v"(r4), "+v"(r5), "+v"(r6));   /* all here, whole: not split up and moved to their uses */
     }
-    entity_visit<STATS, PREPASS>(sc, L, st, e, ep, masked);
+    EntityRows e;
+    e.shape = r0.x; e.material = r0.y; e.octree_depth = r0.z; e.root_node = (uint32_t)r0.w;
+    e.aabb_min[0] = r1.x; e.aabb_min[1] = r1.y; e.aabb_min[2] = r1.z; e.tri_first = __float_as_uint(r1.w);
+    e.aabb_max[0] = r2.x; e.aabb_max[1] = r2.y; e.aabb_max[2] = r2.z; e.n_tris = __float_as_uint(r2.w);
+    e.region_min[0] = r3.x; e.region_min[1] = r3.y; e.region_min[2] = r3.z; e.shade_base = __float_as_uint(r3.w);
+    e.region_max[0] = r4.x; e.region_max[1] = r4.y; e.region_max[2] = r4.z; e.has_uvs = __float_as_int(r4.w);
+    e.center[0] = r5.x; e.center[1] = r5.y; e.center[2] = r5.z; e.radius = r5.w;
+    e.root_a = (uint32_t)r6.y; e.root_b = (uint32_t)r6.z;
+    entity_visit<STATS, PREPASS>(sc, L, st, e, masked);
 }
 
 template <bool STATS>
@@ -829,7 +862,7 @@ __device__ __forceinline__ int count_lanes(bool p) {
 #endif
 template <bool STATS, bool LOG, bool COOP, bool PREPASS>
 __device__ __forceinline__ void trace_wave(const PtSceneDev &sc, Lane &L, Stats &st, TriLog &lg, float4 *stack, uint32_t *stack1,
-                                           int stride, int done_quota, int leaf_quota, CoopLds *coop, int lane) {
+                                           int stride, int done_quota, int leaf_quota, CoopLds *coop, int lane, bool lds_ents) {
     static_assert(!(LOG && COOP), "the cooperative leaf phase keeps no test log");
     static_assert(!(PREPASS && COOP), "the entity pre-pass belongs to the builds for small scenes");
     constexpr bool SPEC = COOP || (PT_SPEC_LIGHT && !LOG);
@@ -842,7 +875,12 @@ __device__ __forceinline__ void trace_wave(const PtSceneDev &sc, Lane &L, Stats 
         int n_pend = 0;
         if (COOP) {
             n_pend = count_lanes(L.tri_left != 0u);
-            if (n_pend >= leaf_quota || phase_due) { leaf_coop<STATS>(sc, L, st, coop, lane); n_pend = 0; phase_due = false; }
+            if (n_pend >= leaf_quota || phase_due) {
+                const uint64_t c0 = STATS ? wave_clock() : 0;
+                leaf_coop<STATS>(sc, L, st, coop, lane);
+                if (STATS) st.cyc_leaf += wave_clock() - c0;
+                n_pend = 0; phase_due = false;
+            }
         }
         const int n_node = count_lanes(L.mode == M_NODE);
         const int n_done = count_lanes(L.mode == M_DONE);
@@ -866,9 +904,11 @@ __device__ __forceinline__ void trace_wave(const PtSceneDev &sc, Lane &L, Stats 
         }
         /* one of three blocks runs; written as three independent conditionals (not an if / else-if chain): every block
          * then is a plain divergent region that updates the lane state in place */
+        const uint64_t c0 = STATS ? wave_clock() : 0;
         if (which == 0) {
             if (STATS) st.ent_trips++;
-            if (L.mode == M_ENTITY) { if (STATS) st.ent_lanes++; entity_block<STATS, PREPASS, COOP>(sc, L, st); }
+            if (L.mode == M_ENTITY) { if (STATS) st.ent_lanes++; entity_block<STATS, PREPASS, COOP>(sc, L, st, lds_ents); }
+            if (STATS) st.cyc_ent += wave_clock() - c0;
         }
         if (which == 1) {
             int trips = 0;
@@ -881,6 +921,7 @@ __device__ __forceinline__ void trace_wave(const PtSceneDev &sc, Lane &L, Stats 
                 }
             } while ((trips += PT_NODE_GROUP) < PT_TRIPS && PT_KEEP_NODE * __popcll(__ballot(L.mode == M_NODE)) >= n_node &&
                      !(COOP && __popcll(__ballot(L.tri_left != 0u)) >= leaf_quota));
+            if (STATS) st.cyc_node += wave_clock() - c0;
         }
         if (which == 2) {
             if (COOP) {
@@ -892,6 +933,7 @@ __device__ __forceinline__ void trace_wave(const PtSceneDev &sc, Lane &L, Stats 
                     if (STATS) st.leaf_trips++;
                     if (L.tri_left != 0u) { if (STATS) st.leaf_lanes++; leaf_block<STATS, LOG, PREPASS, SPEC>(sc, L, st, lg); }
                 } while (++trips < PT_TRIPS && PT_KEEP_LEAF * __popcll(__ballot(L.tri_left != 0u)) >= n_pend);
+                if (STATS) st.cyc_leaf += wave_clock() - c0;
             }
         }
     }

@@ -32,20 +32,33 @@ __host__ __device__ static inline int stack_levels(int max_depth) { return max_d
 
 /* the node step's look-up tables (pt_child_table.h), made at compile time; every workgroup copies them to the start of its LDS */
 __device__ const ChildTables kChildTablesDev = make_child_tables();
-static constexpr int kTableWords = (int)(sizeof(ChildTables) / 4), kTableQuads = (int)(sizeof(ChildTables) / 16);
-static_assert(sizeof(ChildTables) % 16 == 0, "the stack frames behind the tables are 16-byte words");
+static constexpr int kTableWords = (int)(sizeof(ChildTables) / 4);
+static constexpr int kEntityQuads = (int)(kLdsEntities * sizeof(PtEntity) / 16);
+/* 16-byte words of LDS in front of the stack frames: the tables, then room for the entity records of a small scene */
+static constexpr int kConstQuads = (int)(sizeof(ChildTables) / 16) + kEntityQuads;
+static_assert(sizeof(ChildTables) % 16 == 0 && sizeof(PtEntity) % 16 == 0, "the stack frames behind the constants are 16-byte words");
+static_assert(sizeof(ChildTables) == kEntLdsByte, "entity_block addresses the entity records by this offset");
 
-__device__ __forceinline__ void load_child_tables(float4 *lds) {
+/* Fills the constant part of a workgroup's LDS; returns whether the scene's entity records are in it (entity_block). */
+__device__ __forceinline__ bool load_lds_constants(float4 *lds, const PtSceneDev &sc) {
     /* the node step addresses the tables from LDS address 0: the kernels here have no static LDS in front of the dynamic segment */
     if ((uint32_t)(uintptr_t)lds != 0u) __builtin_trap();
     const uint32_t *src = reinterpret_cast<const uint32_t *>(&kChildTablesDev);
     uint32_t *dst = reinterpret_cast<uint32_t *>(lds);
     for (int i = threadIdx.x; i < kTableWords; i += kBlock) dst[i] = src[i];
+    const bool ents = kLdsEntities > 0 && sc.n_entities <= kLdsEntities;
+    if (ents) {
+        const float4 *es = reinterpret_cast<const float4 *>(sc.entities);
+        float4 *ed = lds + sizeof(ChildTables) / 16;
+        const int n = sc.n_entities * (int)(sizeof(PtEntity) / 16);
+        for (int i = threadIdx.x; i < n; i += kBlock) ed[i] = es[i];
+    }
     __syncthreads();
+    return ents;
 }
 
-/* dynamic LDS of a workgroup: the tables, the stack frames (16-byte words, then 4-byte words), then one CoopLds per wave.
- * `lds` here is the start of the stack frames. */
+/* dynamic LDS of a workgroup: the tables and entity records, the stack frames (16-byte words, then 4-byte words), then one
+ * CoopLds per wave.  `lds` here is the start of the stack frames. */
 __device__ __forceinline__ CoopLds *coop_area(float4 *lds, int max_depth) {
     char *base = reinterpret_cast<char *>(lds) + (size_t)stack_levels(max_depth) * kBlock * (sizeof(float4) + sizeof(uint32_t));
     return reinterpret_cast<CoopLds *>(base) + (threadIdx.x >> 6);
@@ -75,6 +88,25 @@ __device__ __forceinline__ float fast_pow(float x, float y) {
 __device__ __forceinline__ float hdri_pow(float x, float y) {
     if (x > 0.0f) return fast_pow(x, y);
     return y == 0.0f ? 1.0f : (y > 0.0f ? 0.0f : __builtin_inff());
+}
+/* acos(x), |x| <= 1 (values just above 1, a rounding of the normalisation in front of it, give 0 or pi): the polynomial
+ * of Abramowitz & Stegun 4.4.46, sqrt(1 - x) * P7(x) with |error| <= 2e-8 before rounding, mirrored for negative x.  Twelve
+ * instructions; the library's acosf is 130, and it is evaluated by every wave in every shading round for the few lanes
+ * whose ray left the scene.  The result moves the environment look-up by 1e-4 of a texel at most. */
+__device__ __forceinline__ float fast_acos(float x) {
+    PT_SHADING_FP
+    const float a = fabsf(x);
+    const float s = __builtin_amdgcn_sqrtf(fmaxf(1.0f - a, 0.0f));
+    float p = -0.0012624911f;
+    p = p * a + 0.0066700901f;
+    p = p * a - 0.0170881256f;
+    p = p * a + 0.0308918810f;
+    p = p * a - 0.0501743046f;
+    p = p * a + 0.0889789874f;
+    p = p * a - 0.2145988016f;
+    p = p * a + 1.5707963050f;
+    const float r = s * p;
+    return (__float_as_uint(x) >> 31) ? 3.14159265f - r : r;
 }
 /* sin / cos of 2*pi*rev, rev in (0,1]: v_sin_f32 / v_cos_f32 take revolutions */
 __device__ __forceinline__ float sin_rev(float rev) { return __builtin_amdgcn_sinf(rev); }
@@ -167,7 +199,7 @@ __device__ __forceinline__ V3 sample_hdri(const PtSceneDev &sc, V3 v, Stats &st)
     if (STATS) st.env_lookups++;
     const float rn = fast_rsq(v.x * v.x + v.z * v.z);
     const float vpx = v.x * rn, vpz = v.z * rn;
-    float x_c = ((acosf(vpz) * ((__float_as_uint(vpx) >> 31) ? -1.0f : 1.0f)) * (1.0f / (2.0f * 3.14159265f))) + 0.5f;
+    float x_c = ((fast_acos(vpz) * ((__float_as_uint(vpx) >> 31) ? -1.0f : 1.0f)) * (1.0f / (2.0f * 3.14159265f))) + 0.5f;
     const float y_c = fminf(1.0f - ((v.y + 1.0f) * 0.5f), 0.99f);
     x_c += sc.hdri_rot_offset;
     x_c = __builtin_amdgcn_fractf(x_c);      /* fmodf(x, 1) for x >= 0: both are exact */
@@ -351,8 +383,8 @@ __global__ void __launch_bounds__(kBlock) trace_kernel(PtSceneDev sc, const floa
                                                        pt_hit *__restrict__ hits, int32_t *__restrict__ log, int log_stride,
                                                        unsigned long long *__restrict__ stats) {
     extern __shared__ float4 lds_raw[];
-    float4 *lds_stack = lds_raw + kTableQuads;
-    load_child_tables(lds_raw);
+    float4 *lds_stack = lds_raw + kConstQuads;
+    const bool lds_ents = load_lds_constants(lds_raw, sc);
     float4 *stack = lds_stack + threadIdx.x;
     uint32_t *stack1 = reinterpret_cast<uint32_t *>(lds_stack + stack_levels(sc.max_depth) * kBlock) + threadIdx.x;
     CoopLds *coop = coop_area(lds_stack, sc.max_depth);
@@ -397,7 +429,7 @@ __global__ void __launch_bounds__(kBlock) trace_kernel(PtSceneDev sc, const floa
         }
         first = false;
         if (__ballot(L.mode != M_IDLE) == 0ull) break;
-        trace_wave<true, LOG, !LOG, LOG>(sc, L, st, lg, stack, stack1, kBlock, kDoneQuota, kLeafQuota, coop, threadIdx.x & 63);
+        trace_wave<true, LOG, !LOG, LOG>(sc, L, st, lg, stack, stack1, kBlock, kDoneQuota, kLeafQuota, coop, threadIdx.x & 63, lds_ents);
     }
     if (stats) {
         flush_stat(&stats[0], st.segments);
@@ -523,8 +555,8 @@ __device__ __forceinline__ uint32_t udiv(uint32_t n, const UDiv &d) {
 template <bool STATS, int WAVES, bool COOP, bool PREPASS>
 __global__ void __launch_bounds__(kBlock, WAVES) render_kernel(RenderParams P) {
     extern __shared__ float4 lds_raw[];
-    float4 *lds_stack = lds_raw + kTableQuads;
-    load_child_tables(lds_raw);
+    float4 *lds_stack = lds_raw + kConstQuads;
+    const bool lds_ents = load_lds_constants(lds_raw, P.sc);
     float4 *stack = lds_stack + threadIdx.x;
     uint32_t *stack1 = reinterpret_cast<uint32_t *>(lds_stack + stack_levels(P.sc.max_depth) * kBlock) + threadIdx.x;
     CoopLds *coop = coop_area(lds_stack, P.sc.max_depth);
@@ -565,6 +597,7 @@ __global__ void __launch_bounds__(kBlock, WAVES) render_kernel(RenderParams P) {
     L.tri_left = 0u;
     Stats st;
     stats_zero(st);
+    const uint64_t cyc_begin = STATS ? wave_clock() : 0;
     TriLog lg;
     lg.p = nullptr; lg.cap = 0;
 
@@ -700,7 +733,9 @@ __global__ void __launch_bounds__(kBlock, WAVES) render_kernel(RenderParams P) {
             if (__ballot(!(meta & kDoneBit)) == 0ull) break;      /* every lane is out of work: the grid drains */
             continue;                                /* e.g. lanes that drew an out-of-image slot ask again */
         }
-        trace_wave<STATS, false, COOP, PREPASS>(P.sc, L, st, lg, stack, stack1, kBlock, P.done_quota, P.leaf_quota, coop, lane);
+        const uint64_t c0 = STATS ? wave_clock() : 0;
+        trace_wave<STATS, false, COOP, PREPASS>(P.sc, L, st, lg, stack, stack1, kBlock, P.done_quota, P.leaf_quota, coop, lane, lds_ents);
+        if (STATS) st.cyc_trace += wave_clock() - c0;
     }
     if (STATS && P.stats) {
         flush_stat(&P.stats[0], st.segments);
@@ -719,6 +754,14 @@ __global__ void __launch_bounds__(kBlock, WAVES) render_kernel(RenderParams P) {
         flush_stat(&P.stats[12], lane == 0 ? st.node_trips : 0u);
         flush_stat(&P.stats[13], lane == 0 ? st.leaf_trips : 0u);
         flush_stat(&P.stats[14], lane == 0 ? st.front_trips : 0u);
+        /* wave life times: in the blocks, in trace_wave, and from the kernel's first instruction to here */
+        if (lane == 0) {
+            atomicAdd(&P.stats[15], (unsigned long long)st.cyc_ent);
+            atomicAdd(&P.stats[16], (unsigned long long)st.cyc_node);
+            atomicAdd(&P.stats[17], (unsigned long long)st.cyc_leaf);
+            atomicAdd(&P.stats[18], (unsigned long long)st.cyc_trace);
+            atomicAdd(&P.stats[19], (unsigned long long)(wave_clock() - cyc_begin));
+        }
     }
 }
 
@@ -783,7 +826,7 @@ SlicePlan make_slice_plan(int sample_begin, int sample_end, int n_split, int64_t
 }
 
 static size_t stack_bytes(int max_depth) {
-    return sizeof(ChildTables) + (size_t)stack_levels(max_depth) * kBlock * (sizeof(float4) + sizeof(uint32_t)) + (kBlock / 64) * sizeof(CoopLds);
+    return (size_t)kConstQuads * 16 + (size_t)stack_levels(max_depth) * kBlock * (sizeof(float4) + sizeof(uint32_t)) + (kBlock / 64) * sizeof(CoopLds);
 }
 
 int launch_trace(const PtSceneDev &sc, const float *d_rays, int64_t n, pt_hit *d_hits, int32_t *d_log, int log_stride,
