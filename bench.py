@@ -219,6 +219,8 @@ def main():
     torch.cuda.synchronize()
     schedule = scene.schedule_counters()
     schedule["wave_time_share"] = scene.block_cycles()
+    nt = max(schedule["node"]["trips"], 1)
+    schedule["node_trip_lanes"] = dict(walking=schedule["node"]["lanes"] / nt, **{k: v / nt for k, v in scene.node_trip_idle_lanes().items()})
     scene.set_profiling(True)
     fence()
     kernel_ms = []

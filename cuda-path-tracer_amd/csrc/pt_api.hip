@@ -93,7 +93,7 @@ struct pt_scene {
 
 namespace {
 
-constexpr int kStatSlots = 24;       /* counter block of a counted launch: 7 work counters, 8 scheduling counters, 5 wave life times */
+constexpr int kStatSlots = 24;       /* counter block of a counted launch: 7 work counters, 8 scheduling counters, 5 wave life times, 3 idle-lane counts */
 constexpr int kMaxQueues = 4096;     /* upper bound on the persistent grid (workgroups) */
 
 /*
@@ -1198,15 +1198,15 @@ int pt_scene_schedule_counters(pt_scene *scene, uint64_t out[8]) {
     return 0;
 }
 
-int pt_scene_block_cycles(pt_scene *scene, uint64_t out[5]) {
-    if (!scene || !out) PT_FAIL("pt_scene_block_cycles: null argument");
-    if (!scene->committed) PT_FAIL("pt_scene_block_cycles: scene not committed");
-    if (!scene->stats_valid) PT_FAIL("pt_scene_block_cycles: no render launch with counters since the scene was committed");
+int pt_scene_wave_profile(pt_scene *scene, uint64_t out[8]) {
+    if (!scene || !out) PT_FAIL("pt_scene_wave_profile: null argument");
+    if (!scene->committed) PT_FAIL("pt_scene_wave_profile: scene not committed");
+    if (!scene->stats_valid) PT_FAIL("pt_scene_wave_profile: no render launch with counters since the scene was committed");
     DeviceGuard g(scene->device);
-    if (!g.ok) PT_FAIL("pt_scene_block_cycles: cannot select device");
+    if (!g.ok) PT_FAIL("pt_scene_wave_profile: cannot select device");
     unsigned long long h[kStatSlots];
     PT_HIP(hipMemcpy(h, scene->d_stats, sizeof h, hipMemcpyDeviceToHost));
-    for (int i = 0; i < 5; i++) out[i] = h[15 + i];
+    for (int i = 0; i < 8; i++) out[i] = h[15 + i];
     return 0;
 }
 

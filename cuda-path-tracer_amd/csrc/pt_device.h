@@ -69,12 +69,16 @@ struct Stats {
     /* shader-clock cycles the wave spent inside each geometry block and inside trace_wave as a whole (wave-uniform; the
      * clock runs on while other waves of the SIMD issue, so these are shares of a wave's life time, not issue cycles) */
     uint64_t cyc_ent, cyc_node, cyc_leaf, cyc_trace;
+    /* node trips this lane sat out because it had finished its ray (and waits for the shading quorum), because it waits at a
+     * leaf for its triangle run, or for another reason (next entity due, no work left) */
+    uint32_t idle_done, idle_leaf, idle_other;
 };
 __device__ __forceinline__ uint64_t wave_clock() { return __builtin_readcyclecounter(); }
 __device__ __forceinline__ void stats_zero(Stats &s) {
     s.segments = s.aabb_tests = s.node_visits = s.tri_tests = s.env_lookups = s.tex_fetches = s.paths = 0;
     s.ent_lanes = s.node_lanes = s.leaf_lanes = s.front_lanes = s.ent_trips = s.node_trips = s.leaf_trips = s.front_trips = 0;
     s.cyc_ent = s.cyc_node = s.cyc_leaf = s.cyc_trace = 0;
+    s.idle_done = s.idle_leaf = s.idle_other = 0;
 }
 
 struct Best {
@@ -916,7 +920,12 @@ __device__ __forceinline__ void trace_wave(const PtSceneDev &sc, Lane &L, Stats 
             do {
 #pragma unroll
                 for (int u = 0; u < PT_NODE_GROUP; u++) {
-                    if (STATS) st.node_trips++;
+                    if (STATS) {
+                        st.node_trips++;
+                        st.idle_done += L.mode == M_DONE ? 1u : 0u;
+                        st.idle_leaf += L.mode == M_LEAF ? 1u : 0u;
+                        st.idle_other += (L.mode == M_ENTITY || L.mode == M_IDLE) ? 1u : 0u;
+                    }
                     if (L.mode == M_NODE) { if (STATS) st.node_lanes++; node_block<STATS, PREPASS, SPEC>(sc, L, st, stack, stack1, stride); }
                 }
             } while ((trips += PT_NODE_GROUP) < PT_TRIPS && PT_KEEP_NODE * __popcll(__ballot(L.mode == M_NODE)) >= n_node &&

@@ -754,6 +754,9 @@ __global__ void __launch_bounds__(kBlock, WAVES) render_kernel(RenderParams P) {
         flush_stat(&P.stats[12], lane == 0 ? st.node_trips : 0u);
         flush_stat(&P.stats[13], lane == 0 ? st.leaf_trips : 0u);
         flush_stat(&P.stats[14], lane == 0 ? st.front_trips : 0u);
+        flush_stat(&P.stats[20], st.idle_done);
+        flush_stat(&P.stats[21], st.idle_leaf);
+        flush_stat(&P.stats[22], st.idle_other);
         /* wave life times: in the blocks, in trace_wave, and from the kernel's first instruction to here */
         if (lane == 0) {
             atomicAdd(&P.stats[15], (unsigned long long)st.cyc_ent);

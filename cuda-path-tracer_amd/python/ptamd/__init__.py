@@ -58,7 +58,7 @@ ABI_SYMBOLS = [
     "pt_scene_add_mesh", "pt_scene_add_sphere", "pt_scene_set_hdri", "pt_scene_commit", "pt_scene_clone", "pt_scene_save", "pt_scene_load", "pt_octree_builds", "pt_scene_octree_info",
     "pt_scene_octree_dump", "pt_scene_device_bytes", "pt_trace_rays", "pt_camera_rays", "pt_sample_hdri", "pt_sample_material", "pt_box_intersects_triangle", "pt_child_tables", "pt_render_accumulate", "pt_render_accumulate_tiles", "pt_render_slices",
     "pt_render_accumulate_noalloc", "pt_noalloc_max_partial_bytes", "pt_scene_set_launch", "pt_scene_get_launch", "pt_scene_render_residency",
-    "pt_scene_set_profiling", "pt_scene_schedule_counters", "pt_scene_block_cycles", "pt_scene_last_render_kernel_ms", "pt_compound_buffers", "pt_reduce_sum", "pt_apply_filter", "pt_make_gaussian", "pt_make_mean", "pt_normalize_image", "pt_apply_threshold",
+    "pt_scene_set_profiling", "pt_scene_schedule_counters", "pt_scene_wave_profile", "pt_scene_last_render_kernel_ms", "pt_compound_buffers", "pt_reduce_sum", "pt_apply_filter", "pt_make_gaussian", "pt_make_mean", "pt_normalize_image", "pt_apply_threshold",
     "pt_image_add", "pt_apply_aces", "pt_gamma_correct", "pt_post_chain", "pt_malloc", "pt_free", "pt_memset", "pt_upload",
     "pt_download", "pt_stream_synchronize",
 ]
@@ -108,7 +108,7 @@ def lib():
         L.pt_scene_render_residency.argtypes = [vp, C.POINTER(C.c_int)]
         L.pt_scene_set_profiling.argtypes = [vp, i32]
         L.pt_scene_schedule_counters.argtypes = [vp, vp]
-        L.pt_scene_block_cycles.argtypes = [vp, vp]
+        L.pt_scene_wave_profile.argtypes = [vp, vp]
         L.pt_scene_last_render_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
         L.pt_compound_buffers.argtypes = [i32, vp, vp, i64, i32, vp]
         L.pt_reduce_sum.argtypes = [i32, vp, i32, C.POINTER(C.c_int), C.POINTER(vp), i64]
@@ -372,14 +372,19 @@ class Scene:
 
     def block_cycles(self):
         """Shares of the waves' life time in the last counted launch: entity / node / leaf blocks, the geometry scheduler
-        around them, and the shade / refill round (pt_scene_block_cycles)."""
-        out = (C.c_uint64 * 5)()
-        check(self.L.pt_scene_block_cycles(self.h, out))
-        ent, node, leaf, trace, total = [int(x) for x in out]
+        around them, and the shade / refill round (pt_scene_wave_profile)."""
+        out = (C.c_uint64 * 8)()
+        check(self.L.pt_scene_wave_profile(self.h, out))
+        ent, node, leaf, trace, total = [int(x) for x in out[:5]]
+        self._idle_lanes = dict(finished=int(out[5]), at_leaf=int(out[6]), other=int(out[7]))
         if total == 0:
             return {}
         return dict(ent=ent / total, node=node / total, leaf=leaf / total, scheduler=(trace - ent - node - leaf) / total,
                     round=(total - trace) / total, wave_cycles=total)
+
+    def node_trip_idle_lanes(self):
+        """Lanes that sat out the node trips of the last counted launch, by reason (sums over all trips; call block_cycles first)."""
+        return dict(self._idle_lanes)
 
     def set_profiling(self, enable=True):
         check(self.L.pt_scene_set_profiling(self.h, int(bool(enable))))
