@@ -152,6 +152,11 @@ def main():
         else:
             dist.init_process_group("gloo", rank=rank, world_size=world)
 
+    def progress(msg):
+        # progress lines on stderr (never inside the timed region): a run of the large configurations is silent for minutes otherwise
+        if rank == 0:
+            print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+
     cfg = S.CONFIGS[args.workload]
     res = tuple(int(x) for x in args.res.split("x")) if args.res else cfg["res"]
     spp = ptdist.effective_spp(args.spp if args.spp else cfg["spp"])
@@ -162,6 +167,7 @@ def main():
     if rank == 0:
         desc = cfg["builder"](res=res)
         t_gen = time.time() - t0
+        progress(f"scene description made in {t_gen:.1f} s")
         t0 = time.time()
         scene, cam = ptamd.scene_from_description(desc, device=dev)
         meshes = [e for e in desc["entities"] if e["kind"] == "mesh"]
@@ -182,6 +188,7 @@ def main():
         if rank == 0 and os.path.exists(share):
             os.remove(share)
     t_upload = time.time() - t0
+    progress(f"scene built and uploaded in {t_upload:.1f} s")
     n_pixels = res[0] * res[1]
     n_split = 4
     n_entities = meta["n_entities"]
@@ -212,11 +219,13 @@ def main():
         torch.cuda.synchronize()
 
     launch = scene.launch()      # the render kernel's launch choices (kernel build, quorum) picked at commit
-    for _ in range(args.warmup):
+    for i in range(args.warmup):
         step()
+        progress(f"warm-up step {i + 1} of {args.warmup} done")
     # one untimed pass with the in-kernel work counters (identical work: same seed, same samples)
     counters = step(want_counters=True)
     torch.cuda.synchronize()
+    progress("counting pass done")
     schedule = scene.schedule_counters()
     schedule["wave_time_share"] = scene.block_cycles()
     nt = max(schedule["node"]["trips"], 1)
@@ -232,6 +241,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     scene.set_profiling(False)
+    progress(f"{args.steps} timed steps done in {elapsed:.2f} s")
 
     cdev = f"cuda:{dev}" if args.backend == "nccl" else "cpu"
     t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
@@ -338,7 +348,9 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             sys.path.insert(0, os.path.join(REPO, "oracle"))
             import oracle_api as O
+            progress("CPU baseline: building the oracle's scene")
             osc, ocam = O.scene_from_description(desc)
+            progress("CPU baseline: rendering")
             cores = min(os.cpu_count() or 1, 16)
             rows = (0, res[1])
             tc = time.perf_counter()

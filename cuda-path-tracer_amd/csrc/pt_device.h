@@ -260,8 +260,19 @@ __device__ __forceinline__ void lane_start_ray(Lane &L, V3 o, V3 d) {
  * interval, entry test).
  */
 /* (the block proper, on a view E of the entity's record: the record itself, or a copy of its rows in registers) */
-template <bool STATS, bool PREPASS, typename E>
-__device__ __forceinline__ void entity_visit(const PtSceneDev &sc, Lane &L, Stats &st, const E &e, bool masked) {
+template <bool STATS, bool LOG, bool PREPASS, bool SPEC>
+__device__ __forceinline__ void leaf_block(const PtSceneDev &sc, Lane &L, Stats &st, TriLog &lg);
+
+/* An experiment, off (PT_TINY_INLINE = 0): a mesh without octree whose run is a single pair of triangles (a quad: a floor, the
+ * walls of a box) tested right here in the builds whose lanes test their own runs (TINY), instead of sending the lane to wait for
+ * a leaf trip -- on the teapot scene, where every ray meets the floor quad, 17 of 64 lanes sit out each node trip waiting for
+ * that one pair.  Measured: teapot 7750 against 8375 Mpaths/s (the pair test then runs inside every entity trip, at that trip's
+ * 58 % occupancy, instead of in a fifth as many leaf trips), Cornell box +2 % at 32 spp and equal at 256. */
+#ifndef PT_TINY_INLINE
+#define PT_TINY_INLINE 0
+#endif
+template <bool STATS, bool PREPASS, bool TINY, bool LOG, typename E>
+__device__ __forceinline__ void entity_visit(const PtSceneDev &sc, Lane &L, Stats &st, const E &e, bool masked, TriLog &lg) {
     const int32_t ei = L.ent;
     L.ent = ei + 1;                       /* default: move on to the next entity, or finish */
     L.mode = next_entity_mode<PREPASS>(sc, L);
@@ -288,6 +299,7 @@ __device__ __forceinline__ void entity_visit(const PtSceneDev &sc, Lane &L, Stat
         L.path = 0;
         L.mode = M_LEAF;
         if (STATS) L.spec_mark = st.node_visits;
+        if (TINY && PT_TINY_INLINE && e.n_tris <= 2u) leaf_block<STATS, LOG, PREPASS, false>(sc, L, st, lg);     /* (leaves the lane at its next entity) */
         return;
     }
     V3 o = L.o, d = L.d;
@@ -332,8 +344,8 @@ struct EntityRows {
     float region_min[3]; uint32_t shade_base; float region_max[3]; int32_t has_uvs; float center[3]; float radius; uint32_t root_a, root_b;
 };
 
-template <bool STATS, bool PREPASS, bool TOGETHER>
-__device__ __forceinline__ void entity_block(const PtSceneDev &sc, Lane &L, Stats &st, bool lds_ents) {
+template <bool STATS, bool PREPASS, bool TOGETHER, bool LOG>
+__device__ __forceinline__ void entity_block(const PtSceneDev &sc, Lane &L, Stats &st, bool lds_ents, TriLog &lg) {
     const bool masked = PREPASS && uses_entity_mask(sc);
     if (masked) {
         const uint32_t left = L.emask >> L.ent;
@@ -356,7 +368,7 @@ __device__ __forceinline__ void entity_block(const PtSceneDev &sc, Lane &L, Stat
          * field by field where it is used, every decision (shape, box, octree depth, root region) waits for a fetch of its
          * own, four in a row.  Pays for scenes of one large mesh (+2 % with 871 k triangles); scenes of many small meshes lose by
          * it (box scene -6 %: most trips end at the box test). */
-        if (!TOGETHER) { entity_visit<STATS, PREPASS>(sc, L, st, *ep, masked); return; }
+        if (!TOGETHER) { entity_visit<STATS, PREPASS, !TOGETHER, LOG>(sc, L, st, *ep, masked, lg); return; }
         r0 = reinterpret_cast<const iv4 *>(ep)[0];
         r1 = reinterpret_cast<const fv4 *>(ep)[1]; r2 = reinterpret_cast<const fv4 *>(ep)[2];
         r3 = reinterpret_cast<const fv4 *>(ep)[3]; r4 = reinterpret_cast<const fv4 *>(ep)[4];
@@ -372,7 +384,7 @@ __device__ __forceinline__ void entity_block(const PtSceneDev &sc, Lane &L, Stat
     e.region_max[0] = r4.x; e.region_max[1] = r4.y; e.region_max[2] = r4.z; e.has_uvs = __float_as_int(r4.w);
     e.center[0] = r5.x; e.center[1] = r5.y; e.center[2] = r5.z; e.radius = r5.w;
     e.root_a = (uint32_t)r6.y; e.root_b = (uint32_t)r6.z;
-    entity_visit<STATS, PREPASS>(sc, L, st, e, masked);
+    entity_visit<STATS, PREPASS, !TOGETHER, LOG>(sc, L, st, e, masked, lg);
 }
 
 template <bool STATS>
@@ -911,7 +923,7 @@ __device__ __forceinline__ void trace_wave(const PtSceneDev &sc, Lane &L, Stats 
         const uint64_t c0 = STATS ? wave_clock() : 0;
         if (which == 0) {
             if (STATS) st.ent_trips++;
-            if (L.mode == M_ENTITY) { if (STATS) st.ent_lanes++; entity_block<STATS, PREPASS, COOP>(sc, L, st, lds_ents); }
+            if (L.mode == M_ENTITY) { if (STATS) st.ent_lanes++; entity_block<STATS, PREPASS, COOP, LOG>(sc, L, st, lds_ents, lg); }
             if (STATS) st.cyc_ent += wave_clock() - c0;
         }
         if (which == 1) {
