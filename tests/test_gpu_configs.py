@@ -95,6 +95,16 @@ def test_heavy_instantiations_match_oracle(pt, oracle, scenes, name, monkeypatch
     if len(tertiary):
         _check_trace(g, c, tertiary, 96)
     _check_render(pt, g, cam_g, c, cam_c, res, 32)
+    # scheduling diagnostics of that counted launch: consistent with each other and with the work counters
+    sched = g.schedule_counters()
+    shares = g.block_cycles()
+    idle = g.node_trip_idle_lanes()
+    assert all(0.0 < sched[k]["occupancy"] <= 1.0 for k in ("ent", "node", "leaf", "front"))
+    assert sched["front"]["lanes"] >= res[0] * res[1] * 32          # every path is shaded or ended at least once
+    assert abs(sum(shares[k] for k in ("ent", "node", "leaf", "scheduler", "round")) - 1.0) < 1e-9
+    assert all(shares[k] > 0.0 for k in ("ent", "node", "leaf", "scheduler", "round"))
+    assert sched["node"]["lanes"] + sum(idle.values()) <= 64 * sched["node"]["trips"]
+    assert idle["finished"] > 0
     if name == "synthetic-3wave":
         # configuration 5 ends with the 5x5 bilateral filter on the tone-mapped image: whole post chain vs oracle
         img_sum = pt.render_image(g, cam_g, 32, seed=1337)
