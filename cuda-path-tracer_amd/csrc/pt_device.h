@@ -876,7 +876,7 @@ __device__ __forceinline__ int count_lanes(bool p) {
 #ifndef PT_SPEC_LIGHT
 #define PT_SPEC_LIGHT 0
 #endif
-template <bool STATS, bool LOG, bool COOP, bool PREPASS>
+template <bool STATS, bool LOG, bool COOP, bool PREPASS, bool MULTI>
 __device__ __forceinline__ void trace_wave(const PtSceneDev &sc, Lane &L, Stats &st, TriLog &lg, float4 *stack, uint32_t *stack1,
                                            int stride, int done_quota, int leaf_quota, CoopLds *coop, int lane, bool lds_ents) {
     static_assert(!(LOG && COOP), "the cooperative leaf phase keeps no test log");
@@ -921,8 +921,9 @@ __device__ __forceinline__ void trace_wave(const PtSceneDev &sc, Lane &L, Stats 
              * sit out each node trip that way -- but the trip is dear (box test, octree entry, the root's child set), and
              * batching more lanes into it pays: teapot +4.5 %, 871 k-triangle mesh with floor +1.9 %; running it EARLIER, as
              * soon as 8 or 16 lanes wait, costs 10 % and 2.6 %.  Scenes of one entity meet the block only with the fresh rays
-             * of a round, all at once, and the pre-pass builds skip most visits anyway: no weight there (-0.3 %, -0.7 %). */
-            const int ew = (!PREPASS && sc.n_entities > 1) ? 2 : 1;
+             * of a round, all at once, and the pre-pass builds skip most visits anyway: no weight there (-0.3 %, -0.7 %).
+             * MULTI: the instantiations for scenes of two and more entities that have no pre-pass. */
+            constexpr int ew = MULTI ? 2 : 1;           /* (an instantiation of its own: as a run-time weight it cost the single-entity scenes 0.6 %) */
             which = (n_ent >= ew * n_node && n_ent >= ew * n_leaf) ? 0 : (!leaf_first ? 1 : 2);
         }
         /* one of three blocks runs; written as three independent conditionals (not an if / else-if chain): every block

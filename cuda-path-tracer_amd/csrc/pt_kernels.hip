@@ -429,7 +429,7 @@ __global__ void __launch_bounds__(kBlock) trace_kernel(PtSceneDev sc, const floa
         }
         first = false;
         if (__ballot(L.mode != M_IDLE) == 0ull) break;
-        trace_wave<true, LOG, !LOG, LOG>(sc, L, st, lg, stack, stack1, kBlock, kDoneQuota, kLeafQuota, coop, threadIdx.x & 63, lds_ents);
+        trace_wave<true, LOG, !LOG, LOG, false>(sc, L, st, lg, stack, stack1, kBlock, kDoneQuota, kLeafQuota, coop, threadIdx.x & 63, lds_ents);
     }
     if (stats) {
         flush_stat(&stats[0], st.segments);
@@ -552,8 +552,9 @@ __device__ __forceinline__ uint32_t udiv(uint32_t n, const UDiv &d) {
     return (t + ((n - t) >> d.sh1)) >> d.sh2;
 }
 
-template <bool STATS, int WAVES, bool COOP, bool PREPASS>
+template <bool STATS, int WAVES, bool COOP, bool PREPASS, bool MULTI>
 __global__ void __launch_bounds__(kBlock, WAVES) render_kernel(RenderParams P) {
+    static_assert(!(PREPASS && MULTI), "the entity pre-pass and the weighted entity rule are alternatives");
     extern __shared__ float4 lds_raw[];
     float4 *lds_stack = lds_raw + kConstQuads;
     const bool lds_ents = load_lds_constants(lds_raw, P.sc);
@@ -734,7 +735,7 @@ __global__ void __launch_bounds__(kBlock, WAVES) render_kernel(RenderParams P) {
             continue;                                /* e.g. lanes that drew an out-of-image slot ask again */
         }
         const uint64_t c0 = STATS ? wave_clock() : 0;
-        trace_wave<STATS, false, COOP, PREPASS>(P.sc, L, st, lg, stack, stack1, kBlock, P.done_quota, P.leaf_quota, coop, lane, lds_ents);
+        trace_wave<STATS, false, COOP, PREPASS, MULTI>(P.sc, L, st, lg, stack, stack1, kBlock, P.done_quota, P.leaf_quota, coop, lane, lds_ents);
         if (STATS) st.cyc_trace += wave_clock() - c0;
     }
     if (STATS && P.stats) {
@@ -890,26 +891,31 @@ int launch_render(RenderParams p, int n_cu, int max_queues, bool heavy, hipStrea
     p.n_queues = (uint32_t)blocks;
     p.items_per_queue = (uint32_t)(((uint64_t)p.n_items + (uint64_t)blocks - 1) / (uint64_t)blocks);
     const dim3 grid((unsigned)blocks), block(kBlock);
+    /* scenes of several entities without the entity pre-pass run the instantiations with the weighted entity rule (trace_wave) */
+    const bool prepass = !heavy && p.sc.n_entities >= kPrepassMinEntities && p.sc.n_entities <= 31;
+    const bool multi = !prepass && p.sc.n_entities > 1;
+#define PT_LAUNCH(WAVES, COOP, PREPASS, MULTI)                                                                                  \
+    do {                                                                                                                        \
+        if (p.stats) hipLaunchKernelGGL((render_kernel<true, WAVES, COOP, PREPASS, MULTI>), grid, block, lds, stream, p);        \
+        else hipLaunchKernelGGL((render_kernel<false, WAVES, COOP, PREPASS, MULTI>), grid, block, lds, stream, p);               \
+    } while (0)
     if (heavy) {
         /* deep octrees need so much LDS for their stacks that fewer workgroups fit: the build for 3 waves per SIMD
          * then has the larger register budget for the same residency */
         if (per_cu >= kWavesHeavy) {
-            if (p.stats) hipLaunchKernelGGL((render_kernel<true, kWavesHeavy, true, false>), grid, block, lds, stream, p);
-            else hipLaunchKernelGGL((render_kernel<false, kWavesHeavy, true, false>), grid, block, lds, stream, p);
+            if (multi) PT_LAUNCH(kWavesHeavy, true, false, true);
+            else PT_LAUNCH(kWavesHeavy, true, false, false);
         } else {
-            if (p.stats) hipLaunchKernelGGL((render_kernel<true, 3, true, false>), grid, block, lds, stream, p);
-            else hipLaunchKernelGGL((render_kernel<false, 3, true, false>), grid, block, lds, stream, p);
+            if (multi) PT_LAUNCH(3, true, false, true);
+            else PT_LAUNCH(3, true, false, false);
         }
     } else {
         /* scenes of many small entities get the instantiation with the entity pre-pass */
-        if (p.sc.n_entities >= kPrepassMinEntities && p.sc.n_entities <= 31) {
-            if (p.stats) hipLaunchKernelGGL((render_kernel<true, kWavesLight, false, true>), grid, block, lds, stream, p);
-            else hipLaunchKernelGGL((render_kernel<false, kWavesLight, false, true>), grid, block, lds, stream, p);
-        } else {
-            if (p.stats) hipLaunchKernelGGL((render_kernel<true, kWavesLight, false, false>), grid, block, lds, stream, p);
-            else hipLaunchKernelGGL((render_kernel<false, kWavesLight, false, false>), grid, block, lds, stream, p);
-        }
+        if (prepass) PT_LAUNCH(kWavesLight, false, true, false);
+        else if (multi) PT_LAUNCH(kWavesLight, false, false, true);
+        else PT_LAUNCH(kWavesLight, false, false, false);
     }
+#undef PT_LAUNCH
     PT_HIP(hipGetLastError());
     return 0;
 }
