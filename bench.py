@@ -116,6 +116,12 @@ def main():
         # no launcher: run the ranks as children of this process (which has not initialised any GPU)
         sys.exit(launch_ranks(args.gpus))
 
+    # The one JSON line goes to the real stdout; everything else that writes to file descriptor 1 from here on (RCCL's and
+    # gloo's start-up banners, which come from native code) goes to stderr.
+    json_fd = os.dup(1)
+    sys.stdout.flush()
+    os.dup2(2, 1)
+
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -393,7 +399,7 @@ def main():
             "scene_by_rank": {"build_upload_s": [b[0] for b in build_info], "octree_builds": [b[1] for b in build_info]},
             "scene_device_bytes": sbytes, "library_source_hash": ptamd.source_hash(), "backend": args.backend if use_dist else None,
         }
-        print(json.dumps(line), flush=True)
+        os.write(json_fd, (json.dumps(line) + "\n").encode())
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
