@@ -126,6 +126,7 @@ struct Lane {
     int32_t a;
     /* triangle run (octree leaf or brute-force mesh) */
     uint32_t tri_cur, tri_left;   /* byte offset of the run's next triangle pair, triangles still to test (0: no run pending) */
+    V3 fr;                        /* clamped reciprocals of d, in the builds that keep them (lane_start_ray) */
     uint32_t spec_mark;           /* counting builds: the lane's node_visits when its pending leaf was entered (see node_block, SPEC) */
     /* a run that accepted a test shows in best.entity (== ent - 1: an entity is visited once per ray and an octree walk
      * ends with the first leaf that accepts); a run that is an octree leaf shows in path != 0 */
@@ -244,8 +245,18 @@ __device__ __forceinline__ int next_entity_mode(const PtSceneDev &sc, const Lane
     return L.ent >= sc.n_entities ? M_DONE : M_ENTITY;
 }
 
+/* The clamped reciprocals of the ray direction (Ray::recalc_fracs, src/geometry.cuh: three IEEE divisions) are needed by every
+ * entity visit.  The builds for scenes of several entities whose lanes have registers to spare (the ones without the cooperative
+ * phase) keep them in the lane state from the start of the ray; the others make them in the visit, once per ray there anyway. */
+#ifndef PT_KEEP_FRACS
+#define PT_KEEP_FRACS 1
+#endif
+__host__ __device__ constexpr bool keeps_fracs(bool coop, bool prepass, bool multi) { return PT_KEEP_FRACS && !coop && (prepass || multi); }
+
+template <bool KEEP_FR>
 __device__ __forceinline__ void lane_start_ray(Lane &L, V3 o, V3 d) {
     L.o = o; L.d = d;
+    if (KEEP_FR) L.fr = mk(clamp_frac(d.x), clamp_frac(d.y), clamp_frac(d.z));
     L.best.t = FLT_MAX; L.best.bu = 0.f; L.best.bv = 0.f; L.best.entity = -1; L.best.rec = 0;
     L.ent = 0;
     L.tri_left = 0u;
@@ -271,7 +282,7 @@ __device__ __forceinline__ void leaf_block(const PtSceneDev &sc, Lane &L, Stats 
 #ifndef PT_TINY_INLINE
 #define PT_TINY_INLINE 0
 #endif
-template <bool STATS, bool PREPASS, bool TINY, bool LOG, typename E>
+template <bool STATS, bool PREPASS, bool TINY, bool LOG, bool KEEP_FR, typename E>
 __device__ __forceinline__ void entity_visit(const PtSceneDev &sc, Lane &L, Stats &st, const E &e, bool masked, TriLog &lg) {
     const int32_t ei = L.ent;
     L.ent = ei + 1;                       /* default: move on to the next entity, or finish */
@@ -291,7 +302,7 @@ __device__ __forceinline__ void entity_visit(const PtSceneDev &sc, Lane &L, Stat
         return;
     }
     if (STATS && !masked) st.aabb_tests++;        /* (the pre-pass has counted the box tests of all meshes) */
-    const V3 fr = mk(clamp_frac(L.d.x), clamp_frac(L.d.y), clamp_frac(L.d.z));
+    const V3 fr = KEEP_FR ? L.fr : mk(clamp_frac(L.d.x), clamp_frac(L.d.y), clamp_frac(L.d.z));
     if (!slab_test(e.aabb_min, e.aabb_max, L.o, fr, L.best.t)) return;
     if (e.octree_depth == 0) {            /* dgf:286-291 */
         if (e.n_tris == 0) return;
@@ -344,7 +355,7 @@ struct EntityRows {
     float region_min[3]; uint32_t shade_base; float region_max[3]; int32_t has_uvs; float center[3]; float radius; uint32_t root_a, root_b;
 };
 
-template <bool STATS, bool PREPASS, bool TOGETHER, bool LOG>
+template <bool STATS, bool PREPASS, bool TOGETHER, bool LOG, bool KEEP_FR>
 __device__ __forceinline__ void entity_block(const PtSceneDev &sc, Lane &L, Stats &st, bool lds_ents, TriLog &lg) {
     const bool masked = PREPASS && uses_entity_mask(sc);
     if (masked) {
@@ -368,7 +379,7 @@ __device__ __forceinline__ void entity_block(const PtSceneDev &sc, Lane &L, Stat
          * field by field where it is used, every decision (shape, box, octree depth, root region) waits for a fetch of its
          * own, four in a row.  Pays for scenes of one large mesh (+2 % with 871 k triangles); scenes of many small meshes lose by
          * it (box scene -6 %: most trips end at the box test). */
-        if (!TOGETHER) { entity_visit<STATS, PREPASS, !TOGETHER, LOG>(sc, L, st, *ep, masked, lg); return; }
+        if (!TOGETHER) { entity_visit<STATS, PREPASS, !TOGETHER, LOG, KEEP_FR>(sc, L, st, *ep, masked, lg); return; }
         r0 = reinterpret_cast<const iv4 *>(ep)[0];
         r1 = reinterpret_cast<const fv4 *>(ep)[1]; r2 = reinterpret_cast<const fv4 *>(ep)[2];
         r3 = reinterpret_cast<const fv4 *>(ep)[3]; r4 = reinterpret_cast<const fv4 *>(ep)[4];
@@ -384,13 +395,13 @@ __device__ __forceinline__ void entity_block(const PtSceneDev &sc, Lane &L, Stat
     e.region_max[0] = r4.x; e.region_max[1] = r4.y; e.region_max[2] = r4.z; e.has_uvs = __float_as_int(r4.w);
     e.center[0] = r5.x; e.center[1] = r5.y; e.center[2] = r5.z; e.radius = r5.w;
     e.root_a = (uint32_t)r6.y; e.root_b = (uint32_t)r6.z;
-    entity_visit<STATS, PREPASS, !TOGETHER, LOG>(sc, L, st, e, masked, lg);
+    entity_visit<STATS, PREPASS, !TOGETHER, LOG, KEEP_FR>(sc, L, st, e, masked, lg);
 }
 
-template <bool STATS>
+template <bool STATS, bool KEEP_FR>
 __device__ __forceinline__ void entity_prepass(const PtSceneDev &sc, Lane &L, Stats &st) {
     if (!uses_entity_mask(sc)) return;
-    const V3 fr = mk(clamp_frac(L.d.x), clamp_frac(L.d.y), clamp_frac(L.d.z));
+    const V3 fr = KEEP_FR ? L.fr : mk(clamp_frac(L.d.x), clamp_frac(L.d.y), clamp_frac(L.d.z));
     uint32_t m = 0u;
     for (int e = 0; e < sc.n_entities; e++) {          /* the same trip count in every lane */
         const PtEntity &en = sc.entities[e];
@@ -931,7 +942,7 @@ __device__ __forceinline__ void trace_wave(const PtSceneDev &sc, Lane &L, Stats 
         const uint64_t c0 = STATS ? wave_clock() : 0;
         if (which == 0) {
             if (STATS) st.ent_trips++;
-            if (L.mode == M_ENTITY) { if (STATS) st.ent_lanes++; entity_block<STATS, PREPASS, COOP, LOG>(sc, L, st, lds_ents, lg); }
+            if (L.mode == M_ENTITY) { if (STATS) st.ent_lanes++; entity_block<STATS, PREPASS, COOP, LOG, keeps_fracs(COOP, PREPASS, MULTI)>(sc, L, st, lds_ents, lg); }
             if (STATS) st.cyc_ent += wave_clock() - c0;
         }
         if (which == 1) {

@@ -419,9 +419,9 @@ __global__ void __launch_bounds__(kBlock) trace_kernel(PtSceneDev sc, const floa
             i += step;
             if (i < n) {
                 st.segments++;
-                lane_start_ray(L, mk(rays[6 * i], rays[6 * i + 1], rays[6 * i + 2]),
+                lane_start_ray<keeps_fracs(!LOG, LOG, false)>(L, mk(rays[6 * i], rays[6 * i + 1], rays[6 * i + 2]),
                                mk(rays[6 * i + 3], rays[6 * i + 4], rays[6 * i + 5]));
-                if (LOG) entity_prepass<true>(sc, L, st);          /* (the logging build is the one without the cooperative phase) */
+                if (LOG) entity_prepass<true, keeps_fracs(!LOG, LOG, false)>(sc, L, st);          /* (the logging build is the one without the cooperative phase) */
                 if (LOG) { lg.p = log + i * log_stride; lg.p[0] = 0; }
             } else {
                 L.mode = M_IDLE;
@@ -726,8 +726,8 @@ __global__ void __launch_bounds__(kBlock, WAVES) render_kernel(RenderParams P) {
             }
             if (go) {
                 if (STATS) st.segments++;
-                lane_start_ray(L, o, d);
-                if (PREPASS) entity_prepass<STATS>(P.sc, L, st);
+                lane_start_ray<keeps_fracs(COOP, PREPASS, MULTI)>(L, o, d);
+                if (PREPASS) entity_prepass<STATS, keeps_fracs(COOP, PREPASS, MULTI)>(P.sc, L, st);
             }
         }
         if (__ballot(L.mode != M_IDLE) == 0ull) {
