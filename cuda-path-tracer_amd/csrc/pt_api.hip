@@ -93,8 +93,7 @@ struct pt_scene {
 
 namespace {
 
-constexpr int kStatSlots = 24;       /* counter block of a counted launch: 7 work counters, 8 scheduling counters, 5 wave life times, 3 idle-lane counts */
-constexpr int kMaxQueues = 4096;     /* upper bound on the persistent grid (workgroups) */
+constexpr int kStatSlots = 28;       /* counter block of a counted launch: 7 work counters, 8 scheduling counters, 5 wave life times, 3 idle-lane counts */
 
 /*
  * Scratch of pt_render_accumulate_noalloc: the work-queue cursors and the slice partials of the render
@@ -103,9 +102,9 @@ constexpr int kMaxQueues = 4096;     /* upper bound on the persistent grid (work
  * array's name to a kernel: the per-device address is resolved once with hipGetSymbolAddress
  * (scratch_address) and only that pointer is used for kernel arguments and memsets.
  */
-constexpr size_t kScratchTicketBytes = 64 * 1024;                       /* (kMaxQueues + 1) cursors, padded */
+constexpr size_t kScratchTicketBytes = 64 * 1024;                       /* kTicketWords cursor words, padded */
 constexpr size_t kScratchBytes = PT_NOALLOC_SCRATCH_BYTES;
-static_assert((kMaxQueues + 1) * sizeof(uint32_t) <= kScratchTicketBytes, "cursor area too small");
+static_assert(kTicketWords * sizeof(uint32_t) <= kScratchTicketBytes, "cursor area too small");
 static __device__ __align__(256) __attribute__((used)) unsigned char scratch[kScratchBytes];
 
 constexpr int kMaxDevices = 64;
@@ -779,7 +778,7 @@ int pt_scene_commit(pt_scene *scene) {
         if (q >= 1 && q <= 65) { scene->leaf_quota = q; scene->leaf_quota_fixed = true; }
     }
 
-    PT_HIP(hipMalloc((void **)&scene->d_tickets, (kMaxQueues + 1) * sizeof(uint32_t)));
+    PT_HIP(hipMalloc((void **)&scene->d_tickets, kTicketWords * sizeof(uint32_t)));
     PT_HIP(hipMalloc((void **)&scene->d_stats, kStatSlots * sizeof(unsigned long long)));
     PT_HIP(hipMemset(scene->d_stats, 0, kStatSlots * sizeof(unsigned long long)));
     if (scratch_address(scene->device, &scene->scratch)) return 1;
@@ -1010,7 +1009,7 @@ int pt_render_accumulate_tiles(pt_scene *scene, const pt_camera *camera, uint32_
     p.partials = (float *)scene->partials.p;
     p.tickets = scene->d_tickets;
     p.stats = counters ? scene->d_stats : nullptr;
-    PT_HIP(hipMemsetAsync(scene->d_tickets, 0, (kMaxQueues + 1) * sizeof(uint32_t), stream));
+    PT_HIP(hipMemsetAsync(scene->d_tickets, 0, kTicketWords * sizeof(uint32_t), stream));
     /* a share of the tiles leaves the other tiles' partials unwritten: they must read as zero in the compounding kernel */
     if (tile_ranks > 1) PT_HIP(hipMemsetAsync(p.partials, 0, need, stream));
     if (counters) PT_HIP(hipMemsetAsync(scene->d_stats, 0, kStatSlots * sizeof(unsigned long long), stream));
@@ -1068,7 +1067,7 @@ int pt_render_accumulate_noalloc(pt_scene *scene, const pt_camera *camera, uint3
         /* the whole plan at once, as pt_render_accumulate does.  The array keeps the previous call's contents: the cursors
          * must start at zero; every partial the compounding kernel reads is written by the render kernel first */
         p.partials = images;
-        if (launch_zero_words(p.tickets, kMaxQueues + 1, stream)) return 1;
+        if (launch_zero_words(p.tickets, kTicketWords, stream)) return 1;
         if (launch_render(p, scene->n_cu, kMaxQueues, scene->heavy, stream)) return 1;
         if (launch_compound_partials(p.partials, d_split, n_pixels, p.plan, stream)) return 1;
         return 0;
@@ -1097,7 +1096,7 @@ int pt_render_accumulate_noalloc(pt_scene *scene, const pt_camera *camera, uint3
             for (int k = 0; k < g; k++) slice_range(p.plan, z * sps + j + k, q.slice_s0[k], q.slice_s1[k]);
             q.n_items = (uint32_t)((uint64_t)p.mtiles_x * p.mtiles_y * 64 * g);      /* (every tile: tile_first 0, tile_stride 1) */
             q.partials = parts;
-            if (launch_zero_words(q.tickets, kMaxQueues + 1, stream)) return 1;
+            if (launch_zero_words(q.tickets, kTicketWords, stream)) return 1;
             if (launch_render(q, scene->n_cu, kMaxQueues, scene->heavy, stream)) return 1;
             const bool last = j + g >= sps;
             if (launch_fold_partials(sum, parts, g, j == 0, last ? d_split + (size_t)z * n_pixels * 3 : nullptr, n_pixels, stream)) return 1;
@@ -1198,7 +1197,7 @@ int pt_scene_schedule_counters(pt_scene *scene, uint64_t out[8]) {
     return 0;
 }
 
-int pt_scene_wave_profile(pt_scene *scene, uint64_t out[8]) {
+int pt_scene_wave_profile(pt_scene *scene, uint64_t out[11]) {
     if (!scene || !out) PT_FAIL("pt_scene_wave_profile: null argument");
     if (!scene->committed) PT_FAIL("pt_scene_wave_profile: scene not committed");
     if (!scene->stats_valid) PT_FAIL("pt_scene_wave_profile: no render launch with counters since the scene was committed");
@@ -1207,6 +1206,11 @@ int pt_scene_wave_profile(pt_scene *scene, uint64_t out[8]) {
     unsigned long long h[kStatSlots];
     PT_HIP(hipMemcpy(h, scene->d_stats, sizeof h, hipMemcpyDeviceToHost));
     for (int i = 0; i < 8; i++) out[i] = h[15 + i];
+    const unsigned long long waves = h[26] ? h[26] : 1, first_start = ~h[24], last_end = h[25];
+    const unsigned long long mean_start = h[23] / waves, mean_end = (h[23] + h[27]) / waves;
+    out[8] = mean_start - first_start;          /* how long after the first wave a wave starts, on average */
+    out[9] = last_end - mean_end;               /* how long before the last wave a wave ends, on average */
+    out[10] = last_end - first_start;           /* from the first wave's start to the last wave's end */
     return 0;
 }
 

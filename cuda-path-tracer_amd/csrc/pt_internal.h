@@ -79,6 +79,10 @@ inline CamConsts make_cam_consts(const pt_camera &c) {
 
 static constexpr int kMaxSlices = 64;
 
+constexpr int kMaxQueues = 2048;                               /* upper bound on the persistent grid (workgroups): one bit-map word per lane of a wave */
+constexpr int kTicketMapWord = kMaxQueues + 2;
+constexpr int kTicketWords = kTicketMapWord + kMaxQueues / 32;
+
 struct RenderParams {
     PtSceneDev sc;
     pt_camera cam;
@@ -94,7 +98,8 @@ struct RenderParams {
     uint32_t n_items;            /* (this launch's tiles of the mtiles_x * mtiles_y * 64) * slices */
     uint32_t n_queues;           /* == gridDim.x: every workgroup owns one contiguous range of the items */
     uint32_t items_per_queue;    /* ceil(n_items / n_queues): queue q owns items [q * per, (q + 1) * per) cut at n_items */
-    uint32_t *tickets;           /* n_queues cursors, then the number of exhausted queues; zeroed before the launch */
+    uint32_t *tickets;           /* kTicketWords words, zeroed before the launch: n_queues cursors, then the number of exhausted queues;
+                                  * from word kTicketMapWord on, one bit per queue that has been seen exhausted */
     float *partials;             /* [n_split * slices_per_split][H*W][3] */
     unsigned long long *stats;   /* 7 counters, or null */
     UDiv div_slices;             /* item / n_slices */

@@ -599,6 +599,7 @@ __global__ void __launch_bounds__(kBlock, WAVES) render_kernel(RenderParams P) {
     Stats st;
     stats_zero(st);
     const uint64_t cyc_begin = STATS ? wave_clock() : 0;
+    const uint64_t real_begin = STATS ? __builtin_amdgcn_s_memrealtime() : 0;      /* (the constant 100 MHz clock is the one all XCDs share) */
     TriLog lg;
     lg.p = nullptr; lg.cap = 0;
 
@@ -640,26 +641,74 @@ __global__ void __launch_bounds__(kBlock, WAVES) render_kernel(RenderParams P) {
                 if (pool_next >= 64) {
                     if (exhausted) break;
                     uint32_t id = 0xFFFFFFFFu;
-                    if (lane == 0) {
+                    if (COOP) {
+                        /* The builds with the cooperative phase try the ranges one after the other (their lanes have no register to
+                         * spare: the map search below cost them three more spilled registers and 1 % of every launch, and their
+                         * launches, scenes of long walks, lose little to the end of a launch) */
+                        if (lane == 0) {
+                            for (;;) {
+                                const unsigned long long first = (unsigned long long)per_queue * q;
+                                const uint32_t lo = (uint32_t)(first < P.n_items ? first : P.n_items);
+                                const uint32_t hi = (uint32_t)(first + per_queue < P.n_items ? first + per_queue : P.n_items);
+                                const uint32_t t = atomicAdd(&P.tickets[q], 1u);
+                                if (t < hi - lo) { id = lo + t; break; }
+                                /* this range is finished for good; the first draw past its end reports it, and once
+                                 * every range is reported nothing is left anywhere */
+                                if (t == hi - lo) atomicAdd(&P.tickets[nq], 1u);
+                                if (__hip_atomic_load(&P.tickets[nq], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= nq) break;
+                                q = (q + 1u == nq) ? 0u : q + 1u;
+                                if (++probes >= nq) break;               /* every range has been seen empty */
+                            }
+                        }
+                        id = (uint32_t)__builtin_amdgcn_readfirstlane((int)id);
+                        q = (uint32_t)__builtin_amdgcn_readfirstlane((int)q);
+                        probes = (uint32_t)__builtin_amdgcn_readfirstlane((int)probes);
+                    } else {
                         for (;;) {
-                            /* queue q holds items [q * per, min((q + 1) * per, n_items)) */
-                            const unsigned long long first = (unsigned long long)per_queue * q;
-                            const uint32_t lo = (uint32_t)(first < P.n_items ? first : P.n_items);
-                            const uint32_t hi = (uint32_t)(first + per_queue < P.n_items ? first + per_queue : P.n_items);
-                            const uint32_t t = atomicAdd(&P.tickets[q], 1u);
-                            if (t < hi - lo) { id = lo + t; break; }
-                            /* this range is finished for good; the first draw past its end reports it, and once
-                             * every range is reported nothing is left anywhere (without this each wave would
-                             * probe all the ranges before it retires: milliseconds at the end of a launch) */
-                            if (t == hi - lo) atomicAdd(&P.tickets[nq], 1u);
-                            if (__hip_atomic_load(&P.tickets[nq], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= nq) break;
-                            q = (q + 1u == nq) ? 0u : q + 1u;
-                            if (++probes >= nq) break;               /* every range has been seen empty */
+                            /* queue q holds items [q * per, min((q + 1) * per, n_items)); one lane draws */
+                            uint32_t past = 0u;               /* 1: the draw was the first one past the range's end */
+                            if (lane == 0) {
+                                const unsigned long long first = (unsigned long long)per_queue * q;
+                                const uint32_t lo = (uint32_t)(first < P.n_items ? first : P.n_items);
+                                const uint32_t hi = (uint32_t)(first + per_queue < P.n_items ? first + per_queue : P.n_items);
+                                const uint32_t t = atomicAdd(&P.tickets[q], 1u);
+                                if (t < hi - lo) id = lo + t;
+                                else if (t == hi - lo) {
+                                    /* This range is finished for good: the first draw past its end sets the range's bit in the map
+                                     * of exhausted ranges. */
+                                    atomicOr(&P.tickets[kTicketMapWord + (q >> 5)], 1u << (q & 31u));
+                                    past = 1u;
+                                }
+                            }
+                            id = (uint32_t)__builtin_amdgcn_readfirstlane((int)id);
+                            if (id != 0xFFFFFFFFu) break;
+                            past = (uint32_t)__builtin_amdgcn_readfirstlane((int)past);
+                            /* A wave without work reads the map (one word per lane) and goes straight to the next range after its
+                             * own that is not marked -- trying the ranges one by one, an atomic round trip each, cost a wave of an
+                             * unevenly lit image hundreds of trips at the end of a launch (teapot scene: 1.7 ms of a 27 ms launch). */
+                            const uint32_t n_map = (nq + 31u) >> 5;                        /* at most 64 words: kMaxQueues */
+                            uint32_t w = ~0u;
+                            if ((uint32_t)lane < n_map) {
+                                w = __hip_atomic_load(P.tickets + kTicketMapWord + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                const uint32_t bits_here = nq - 32u * (uint32_t)lane;          /* ranges this word stands for */
+                                if (bits_here < 32u) w |= ~0u << bits_here;
+                            }
+                            if (past != 0u && (uint32_t)lane == (q >> 5)) w |= 1u << (q & 31u);        /* (this wave's own mark may not be visible yet) */
+                            const uint32_t open_ranges = ~w;
+                            const uint32_t start = q + 1u;                                 /* first candidate, cyclically */
+                            const uint32_t ls = (start >> 5) & 63u;
+                            const uint32_t from = ~0u << (start & 31u);
+                            const bool wraps = start >= nq;
+                            const uint32_t after = wraps ? 0u : ((uint32_t)lane == ls ? open_ranges & from : ((uint32_t)lane > ls ? open_ranges : 0u));
+                            const uint32_t before = wraps ? open_ranges : ((uint32_t)lane == ls ? open_ranges & ~from : ((uint32_t)lane < ls ? open_ranges : 0u));
+                            unsigned long long lanes_with = __ballot(after != 0u);
+                            uint32_t pick = after;
+                            if (lanes_with == 0ull) { lanes_with = __ballot(before != 0u); pick = before; }
+                            if (lanes_with == 0ull) break;                                 /* every range is marked: nothing is left anywhere */
+                            const int src = __builtin_ctzll(lanes_with);
+                            q = 32u * (uint32_t)src + (uint32_t)__builtin_ctz((uint32_t)__builtin_amdgcn_readlane((int)pick, src));
                         }
                     }
-                    id = (uint32_t)__builtin_amdgcn_readfirstlane((int)id);
-                    q = (uint32_t)__builtin_amdgcn_readfirstlane((int)q);
-                    probes = (uint32_t)__builtin_amdgcn_readfirstlane((int)probes);
                     if (id == 0xFFFFFFFFu) { exhausted = true; break; }
                     /* item -> (tile in macro-tile order, slice) */
                     const uint32_t tidx = udiv(id, P.div_slices);
@@ -764,7 +813,15 @@ __global__ void __launch_bounds__(kBlock, WAVES) render_kernel(RenderParams P) {
             atomicAdd(&P.stats[16], (unsigned long long)st.cyc_node);
             atomicAdd(&P.stats[17], (unsigned long long)st.cyc_leaf);
             atomicAdd(&P.stats[18], (unsigned long long)st.cyc_trace);
-            atomicAdd(&P.stats[19], (unsigned long long)(wave_clock() - cyc_begin));
+            const uint64_t cyc_end = wave_clock();
+            atomicAdd(&P.stats[19], (unsigned long long)(cyc_end - cyc_begin));
+            /* when the waves started and ended, in ticks of the 100 MHz clock: sum and earliest start, latest end, number of waves */
+            const uint64_t real_end = __builtin_amdgcn_s_memrealtime();
+            atomicAdd(&P.stats[23], (unsigned long long)real_begin);
+            atomicMax(&P.stats[24], ~(unsigned long long)real_begin);
+            atomicMax(&P.stats[25], (unsigned long long)real_end);
+            atomicAdd(&P.stats[26], 1ull);
+            atomicAdd(&P.stats[27], (unsigned long long)(real_end - real_begin));
         }
     }
 }

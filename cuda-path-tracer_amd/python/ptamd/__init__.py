@@ -373,14 +373,20 @@ class Scene:
     def block_cycles(self):
         """Shares of the waves' life time in the last counted launch: entity / node / leaf blocks, the geometry scheduler
         around them, and the shade / refill round (pt_scene_wave_profile)."""
-        out = (C.c_uint64 * 8)()
+        out = (C.c_uint64 * 11)()
         check(self.L.pt_scene_wave_profile(self.h, out))
         ent, node, leaf, trace, total = [int(x) for x in out[:5]]
         self._idle_lanes = dict(finished=int(out[5]), at_leaf=int(out[6]), other=int(out[7]))
+        self._span = dict(start_after_first=int(out[8]), end_before_last=int(out[9]), span=int(out[10]))
         if total == 0:
             return {}
         return dict(ent=ent / total, node=node / total, leaf=leaf / total, scheduler=(trace - ent - node - leaf) / total,
                     round=(total - trace) / total, wave_cycles=total)
+
+    def launch_span(self):
+        """In ticks of the chip-wide 100 MHz clock, for the last counted launch: mean delay of a wave's start after the first wave's, mean lead of a wave's
+        end before the last wave's (the tail), and the span from the first start to the last end (call block_cycles first)."""
+        return dict(self._span)
 
     def node_trip_idle_lanes(self):
         """Lanes that sat out the node trips of the last counted launch, by reason (sums over all trips; call block_cycles first)."""

@@ -255,8 +255,10 @@ int pt_scene_schedule_counters(pt_scene *scene, uint64_t out[8]);
  * shade / refill round.  The clock keeps running while other waves of the SIMD issue: these are shares of wall time,
  * not issue cycles, and the counting build of the kernel is slower than the one that is timed.  out[5..7]: lanes that sat out
  * a node trip, summed over all trips, because they had finished their ray and waited for the shading quorum, because they
- * waited at a leaf for its triangle run, or for another reason (next entity due, no work left). */
-int pt_scene_wave_profile(pt_scene *scene, uint64_t out[8]);
+ * waited at a leaf for its triangle run, or for another reason (next entity due, no work left).  out[8..10]: ticks of the chip-wide 100 MHz clock by which a wave
+ * starts after the first wave on average, by which it ends before the last wave on average (the launch's tail), and from the first
+ * wave's start to the last wave's end. */
+int pt_scene_wave_profile(pt_scene *scene, uint64_t out[11]);
 int pt_scene_last_render_kernel_ms(pt_scene *scene, float *ms);
 /* d_out[p] = sum_z d_split[z][p]  (compound_buffers, src/post_processing.cu:243-256); device ptrs */
 int pt_compound_buffers(int device, const float *d_split, float *d_out, int64_t n_pixels,
