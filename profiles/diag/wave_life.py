@@ -17,7 +17,7 @@ split = torch.zeros((4, res[1], res[0], 3), dtype=torch.float32, device="cuda:0"
 stream = torch.cuda.current_stream().cuda_stream
 scene.set_profiling(True)
 n_waves = 256 * 4 * 4
-for spp in (32, 64, 128, 256, 1024):
+for spp in ((32, 64, 128, 256, 1024) if len(sys.argv) < 3 else [int(x) for x in sys.argv[2:]]):
     for counted in (False, True):
         split.zero_()
         scene.render_accumulate(cam, 1337, 0, spp, 4, split.data_ptr(), counted, stream)
